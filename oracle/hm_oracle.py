@@ -1,0 +1,498 @@
+"""CPU ORACLE -- TEST INFRASTRUCTURE ONLY.
+
+A CPU restatement (torch-CPU tensors as the array library, fp32 or fp64) of the reference's
+per-instance latent-code + Sim(3)/SE(3) pose Levenberg-Marquardt loop and everything under it.
+Only `tests/`, `__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg may import this
+file; the product path (`hortimapping_amd/`) never does, and fails loudly without its HIP library.
+
+Parity pin: the reference has no tests, so this oracle is pinned against golden
+vectors captured by running the reference's own code on CPU in the build container
+(`tests/golden/make_golden.py` -> `tests/golden/*.npz`, checked by `tests/test_oracle_golden.py`),
+and directly against the imported reference when the mount is present
+(`tests/test_oracle_vs_reference.py`).
+
+Every function cites the reference lines it restates (paths relative to /root/reference).
+The Jacobian is analytic (no autograd); the render term is the dense per-ray form of
+SURVEY.md 8a "a6", which emits the same rays in the same order as the reference's
+where/unique/scatter_add formulation.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import List, Optional
+
+import numpy as np
+import torch
+
+N_LIN = 9
+SKIP_LAYER = 4
+
+
+# --------------------------------------------------------------------------------------
+# decoder  (deepsdf/networks/deep_sdf_decoder.py:10-110)
+# --------------------------------------------------------------------------------------
+@dataclass
+class FoldedDecoder:
+    """Effective weights after weight-norm folding (deep_sdf_decoder.py:49-54)."""
+    Ws: List[torch.Tensor]
+    bs: List[torch.Tensor]
+    latent_dim: int
+
+    @property
+    def dtype(self):
+        return self.Ws[0].dtype
+
+    def to(self, dtype):
+        return FoldedDecoder([w.to(dtype) for w in self.Ws], [b.to(dtype) for b in self.bs],
+                             self.latent_dim)
+
+
+def fold_decoder(params, dtype=torch.float32) -> FoldedDecoder:
+    """`params`: dict with lin{l}.weight_v/weight_g/bias (l<8), lin8.weight/bias.
+    W_l = g_l * v_l / ||v_l||_row  (torch weight_norm, dim=0; deep_sdf_decoder.py:49-54)."""
+    Ws, bs = [], []
+    for l in range(N_LIN):
+        if f"lin{l}.weight_v" in params:
+            v = torch.as_tensor(np.asarray(params[f"lin{l}.weight_v"]), dtype=torch.float32)
+            g = torch.as_tensor(np.asarray(params[f"lin{l}.weight_g"]), dtype=torch.float32).reshape(-1, 1)
+            w = v * (g / v.norm(dim=1, keepdim=True))
+        else:
+            w = torch.as_tensor(np.asarray(params[f"lin{l}.weight"]), dtype=torch.float32)
+        Ws.append(w.to(dtype).contiguous())
+        bs.append(torch.as_tensor(np.asarray(params[f"lin{l}.bias"]), dtype=torch.float32).to(dtype))
+    return FoldedDecoder(Ws, bs, int(params["latent_dim"]))
+
+
+def _inputs(dec: FoldedDecoder, z, x):
+    x = x.reshape(-1, 3).to(dec.dtype)
+    z = z.reshape(-1).to(dec.dtype)
+    return torch.cat([z.expand(x.shape[0], -1), x], dim=1)  # latent first, xyz last (utils.py:165,185)
+
+
+def decoder_forward(dec: FoldedDecoder, z, x):
+    """sdf values (n,) -- Decoder.forward (deep_sdf_decoder.py:75-110) via decode_sdf (utils.py:144-172)."""
+    u = _inputs(dec, z, x)
+    h = u
+    for l in range(N_LIN):
+        if l == SKIP_LAYER:
+            h = torch.cat([h, u], dim=1)                    # deep_sdf_decoder.py:87-88
+        h = h @ dec.Ws[l].T + dec.bs[l]
+        if l < N_LIN - 1:
+            h = torch.relu(h)                               # :95-103 (dropout inert in eval)
+    return torch.tanh(h[:, 0])                              # :107-108
+
+
+def decoder_jacobian(dec: FoldedDecoder, z, x):
+    """(y (n,), g (n, L+3)) with g = d y / d [z ; x] -- get_batch_sdf_jacobian (utils.py:175-193),
+    restated without autograd (SURVEY.md 8a 'a1/a3 restated')."""
+    u = _inputs(dec, z, x)
+    h = u
+    masks = []
+    for l in range(N_LIN):
+        if l == SKIP_LAYER:
+            h = torch.cat([h, u], dim=1)
+        a = h @ dec.Ws[l].T + dec.bs[l]
+        if l < N_LIN - 1:
+            mk = a > 0
+            masks.append(mk)
+            h = a * mk
+        else:
+            h = a
+    y = torch.tanh(h[:, 0])
+    G = (1.0 - y * y)[:, None] * dec.Ws[8]                  # (n, 512)
+    g_u = torch.zeros_like(u)
+    m = dec.Ws[3].shape[0]
+    for l in range(N_LIN - 2, -1, -1):
+        G = (G * masks[l]) @ dec.Ws[l]
+        if l == SKIP_LAYER:
+            g_u = g_u + G[:, m:]
+            G = G[:, :m]
+    g_u = g_u + G
+    return y, g_u
+
+
+# --------------------------------------------------------------------------------------
+# small helpers (wild_completion/utils.py)
+# --------------------------------------------------------------------------------------
+def pose_jacobian(points, scale_on: bool):
+    """(n,3,P): [ I | -[x]x | x ]  -- get_points_to_pose_jacobian_se3/sim3 (utils.py:197-217,257-276)."""
+    n = points.shape[0]
+    x, y, z = points[:, 0], points[:, 1], points[:, 2]
+    o = torch.zeros_like(x)
+    J = torch.zeros(n, 3, 7 if scale_on else 6, dtype=points.dtype)
+    J[:, 0, 0] = 1; J[:, 1, 1] = 1; J[:, 2, 2] = 1
+    # -[p]x  (the reference stacks *columns*: utils.py:207-212)
+    J[:, 0, 3] = o;  J[:, 0, 4] = z;  J[:, 0, 5] = -y
+    J[:, 1, 3] = -z; J[:, 1, 4] = o;  J[:, 1, 5] = x
+    J[:, 2, 3] = y;  J[:, 2, 4] = -x; J[:, 2, 5] = o
+    if scale_on:
+        J[:, :, 6] = points
+    return J
+
+
+def _hat(w):
+    z = torch.zeros((), dtype=w.dtype)
+    return torch.stack([torch.stack([z, -w[2], w[1]]),
+                        torch.stack([w[2], z, -w[0]]),
+                        torch.stack([-w[1], w[0], z])])
+
+
+def exp_se3(x):
+    """utils.py:220-254.  Tangent order (translation, rotation)."""
+    dt = x.dtype
+    v, w = x[:3], x[3:6]
+    W = _hat(w)
+    W2 = W @ W
+    th = torch.linalg.vector_norm(w)
+    I = torch.eye(3, dtype=dt)
+    if th <= 1e-8:
+        R, J = I, I
+    else:
+        R = I + W * torch.sin(th) / th + W2 * (1.0 - torch.cos(th)) / th ** 2
+        J = I + (1 - torch.cos(th)) / th ** 2 * W + (th - torch.sin(th)) / th ** 3 * W2
+    T = torch.eye(4, dtype=dt)
+    T[:3, :3] = R
+    T[:3, 3] = J @ v
+    return T
+
+
+def exp_sim3(x):
+    """utils.py:279-324, quirks included: in the theta>1e-8 branch c = 0 whenever s <= 1e-8
+    (:314), the theta<=1e-8 branch tests s == 0 exactly (:303-309)."""
+    dt = x.dtype
+    v, w, s = x[:3], x[3:6], x[6]
+    W = _hat(w)
+    W2 = W @ W
+    th = torch.linalg.vector_norm(w)
+    es = torch.exp(s)
+    I = torch.eye(3, dtype=dt)
+    if th <= 1e-8:
+        R = I
+        if s == 0:
+            J = I
+        else:
+            J = (es - 1.0) / s * I
+    else:
+        th2 = th ** 2
+        s2 = s ** 2
+        R = I + W * torch.sin(th) / th + W2 * (1.0 - torch.cos(th)) / th2
+        a = es * torch.sin(th)
+        b = es * torch.cos(th)
+        c = torch.zeros((), dtype=dt) if s <= 1e-8 else (es - 1.0) / s
+        k1 = (a * s + (1 - b) * th) / (s2 + th2)
+        k2 = c - ((b - 1) * s + a * th) / (s2 + th2)
+        J = c * I + k1 * W / th + k2 * W2 / th2
+    T = torch.eye(4, dtype=dt)
+    T[:3, :3] = es * R
+    T[:3, 3] = J @ v
+    return T
+
+
+def huber(res, b: float):
+    """get_robust_res / huber_norm_weights (utils.py:327-358): returns (w*r, w^2)."""
+    a = res.abs()
+    nrm = torch.where(a <= b, a * a, 2 * b * a - b * b)
+    a1 = torch.where(a == 0, torch.ones_like(a), a)
+    w = torch.sqrt(nrm) / a1
+    return w * res, w * w
+
+
+def sdf_to_occ(s, th: float, log_on: bool):
+    """sdf_to_occupancy / sdf_to_occupancy_log (utils.py:125-142) with sigma from loss.py:59-60."""
+    if log_on:
+        sigma = th / 3 * 0.55
+        return torch.sigmoid(-s / sigma)
+    return 0.5 - torch.clamp(s, -th, th) / (2 * th)
+
+
+# --------------------------------------------------------------------------------------
+# residual / Jacobian builders (wild_completion/loss.py)
+# --------------------------------------------------------------------------------------
+def compute_sdf_loss(dec, z, pts_o, scale_on: bool):
+    """loss.py:219-243 -> res (n,), J_pose (n,P), J_code (n,L)."""
+    y, g = decoder_jacobian(dec, z, pts_o)
+    L = dec.latent_dim
+    Jx = pose_jacobian(pts_o.to(dec.dtype), scale_on)
+    J_pose = torch.einsum("ni,nip->np", g[:, L:], Jx)
+    return y, J_pose, g[:, :L]
+
+
+@dataclass
+class RenderOut:
+    res_d: torch.Tensor      # (V,)
+    J_d: torch.Tensor        # (V, P+L)
+    res_m: torch.Tensor      # (V,)
+    J_m: torch.Tensor        # (V, P+L)
+    ray_idx: torch.Tensor    # (V,) ascending (fg first)
+    n_valid: int = 0         # K_v  ball-valid samples
+    n_keep: int = 0          # K_g' samples that went through the Jacobian
+
+
+def compute_render_loss(dec, z, rays, depth_fg, depth_bg, T_oc, sampled_depth, scale_on=False,
+                        log_occ_on=False, occupancy_th=0.01, bbx_radius=0.1, occlusion_on=True,
+                        occlusion_th=0.03, min_valid_sample=100, min_grad_thre=1e-6) -> Optional[RenderOut]:
+    """loss.py:8-217 as a dense per-ray computation."""
+    dt = dec.dtype
+    rays = rays.to(dt); T_oc = T_oc.to(dt); d = sampled_depth.to(dt)
+    R_f = depth_fg.shape[0]
+    obs = torch.cat([depth_fg, depth_bg]).to(dt)                           # :26
+    R, M = rays.shape[0], d.shape[0]
+    p_c = rays[:, None, :] * d[:, None]                                    # :30
+    p_o = (p_c[..., None, :] * T_oc[:3, :3]).sum(-1) + T_oc[:3, 3]         # :32-33
+    valid = torch.linalg.vector_norm(p_o, dim=-1) < bbx_radius             # :38
+    n_valid = int(valid.sum())
+    if n_valid < min_valid_sample:                                         # :43-45
+        return None
+    s = torch.zeros(R, M, dtype=dt)
+    s[valid] = decoder_forward(dec, z, p_o[valid])                         # :48-49
+    occ = torch.where(valid, sdf_to_occ(s, occupancy_th, log_occ_on), torch.zeros_like(s))   # :55-64
+    wg = valid & (s > -occupancy_th) & (s < occupancy_th)                  # :66
+    d_min, d_max = d[0], d[-1]
+    delta_d = (d_max - d_min) / (M - 1)                                    # :75
+    d_term = d_max + delta_d                                               # :78
+    T = torch.cumprod(1 - occ, dim=-1)                                     # :81
+    T_prev = torch.cat([torch.ones(R, 1, dtype=dt), T[:, :-1]], dim=1)
+    prob = occ * T_prev                                                    # :82-91
+    occ_ray = prob.sum(-1)                                                 # :93
+    d_u = (d * prob).sum(-1) + d_term * T[:, -1]                           # :96
+    one_m = 1 - occ
+    dm_do = T[:, -1:] / one_m                                              # :101-102
+    suffix = torch.flip(torch.cumsum(torch.flip(T, dims=[1]), dim=1), dims=[1])
+    de_do = suffix * delta_d / one_m                                       # :103-107
+    if log_occ_on:
+        sigma = occupancy_th / 3 * 0.55
+        do_ds = -occ * (1 - occ) / sigma                                   # :120-121
+    else:
+        do_ds = torch.full_like(occ, -1.0 / (2 * occupancy_th))            # :123
+    keep = wg & (de_do > min_grad_thre)                                    # :111-118
+    is_bg = torch.arange(R) >= R_f
+    if occlusion_on:                                                       # :132-139
+        occl = is_bg & (obs < d_u - occlusion_th) & (obs > 0)
+        keep = keep & ~occl[:, None]
+    obs_eff = torch.where(is_bg, d_term.expand(R), obs)                    # :142,151
+    emit = keep.any(dim=1)
+    ray_idx = torch.nonzero(emit).flatten()                                # ascending = unique() order :160-166
+    res_d = (obs_eff - d_u)[emit]                                          # :155,169
+    res_m = (occ_ray - (~is_bg).to(dt))[emit]                              # :172-176
+    kx, ky = torch.nonzero(keep, as_tuple=True)
+    pts = p_o[kx, ky]
+    _, g = decoder_jacobian(dec, z, pts)                                   # :185-186
+    L = dec.latent_dim
+    Jx = pose_jacobian(pts, scale_on)
+    J_pose = torch.einsum("ni,nip->np", g[:, L:], Jx)
+    Jfull = torch.cat([J_pose, g[:, :L]], dim=1)                           # (K, P+L)
+    ce = torch.where(keep, de_do * do_ds, torch.zeros_like(occ))[kx, ky]   # de_ds :126
+    cm = torch.where(keep, dm_do * do_ds, torch.zeros_like(occ))[kx, ky]   # dm_ds :127
+    E = Jfull.shape[1]
+    remap = torch.full((R,), -1, dtype=torch.long)
+    remap[ray_idx] = torch.arange(ray_idx.shape[0])
+    gi = remap[kx]
+    J_d = torch.zeros(ray_idx.shape[0], E, dtype=dt).index_add_(0, gi, ce[:, None] * Jfull)   # :209-215
+    J_m = torch.zeros(ray_idx.shape[0], E, dtype=dt).index_add_(0, gi, cm[:, None] * Jfull)
+    return RenderOut(res_d, J_d, res_m, J_m, ray_idx, n_valid, int(kx.shape[0]))
+
+
+# --------------------------------------------------------------------------------------
+# LM loop (wild_completion/optimizer.py)
+# --------------------------------------------------------------------------------------
+def default_opt_cfg():
+    """Values of configs/wild_pepper.yaml:19-57 (the `opt:` block)."""
+    return {
+        "scale_on": True,
+        "lm": {"lm_on": True, "lm_eye": False, "lm_lambda_0": 0.1, "s_damp": 1e-3},
+        "recon": {"n_pts": 2000, "cluster_dist_m": 0.01, "robust_th_m": 0.01},
+        "render": {"n_fg_pix": 200, "n_bg_pix": 200, "n_bg_pad": 20, "n_frame": 10,
+                   "n_sample_on_ray": 30, "log_sdf_occ": True, "occ_cutoff_m": 0.01,
+                   "occlusion_on": True, "robust_th_m": 0.05},
+        "weight": {"w_recon": 1.0, "w_depth": 5e-2, "w_mask": 5e-4, "w_codereg": 5e-4},
+        "converge": {"max_iter": 50, "epsilon_g": 1e-4, "epsilon_c": 1e-2, "epsilon_t": 1e-3,
+                     "epsilon_r": 1.0, "epsilon_s": 1e-3},
+        "robust_iter": 5,
+    }
+
+
+def _normal_eq(J, r, rho, weight, count, faithful):
+    """H_t = w * sum_i rho_i J_i^T J_i / n ; b_t = -w * sum_i rho_i J_i^T r_i / n
+    (optimizer.py:152-159,189-190).  `faithful` materialises the (n,E,E) tensor like the reference."""
+    if faithful:
+        Jb = J[:, None, :]
+        H = weight * (rho[:, None, None] * torch.bmm(Jb.transpose(1, 2), Jb)).sum(0) / count
+        b = -weight * (rho[:, None, None] * torch.bmm(Jb.transpose(1, 2), r[:, None, None])).sum(0).squeeze(-1) / count
+    else:
+        H = weight * (J.T @ (rho[:, None] * J)) / count
+        b = -weight * (J.T @ (rho * r)) / count
+    return H, b
+
+
+@dataclass
+class IterTrace:
+    H: torch.Tensor
+    b: torch.Tensor
+    delta: torch.Tensor
+    n_valid: int = 0
+    n_keep: int = 0
+    n_rays: int = 0
+
+
+def render_term(dec, latent, T_ow, render_data, frame_ind, cube_radius, cur_scale, o, scale_on):
+    """Frame loop of optimizer.py:102-132 -> concatenated (res_d, J_d, res_m, J_m) + counters."""
+    dt = dec.dtype
+    M = int(o["render"]["n_sample_on_ray"])
+    res_d, J_d, res_m, J_m = [], [], [], []
+    nv = nk = 0
+    for idx in frame_ind:
+        T_wc = render_data["T_wc"][idx].to(dt)
+        T_oc = T_ow @ T_wc                                                  # :104
+        T_co = torch.inverse(T_oc)                                          # :105
+        depth_range = cube_radius * cur_scale                               # :107
+        d_min = T_co[2, 3] - 1.0 * depth_range                              # :110
+        d_max = T_co[2, 3] + 0.8 * depth_range
+        sd = torch.linspace(float(d_min), float(d_max), M, dtype=dt)        # :111
+        rays = torch.cat([render_data["rays_fg"][idx], render_data["rays_bg"][idx]], 0)   # :113
+        out = compute_render_loss(dec, latent, rays, render_data["depth_fg"][idx],
+                                  render_data["depth_bg"][idx], T_oc, sd, scale_on,
+                                  bool(o["render"]["log_sdf_occ"]), float(o["render"]["occ_cutoff_m"]),
+                                  float(depth_range), bool(o["render"]["occlusion_on"]))     # :116-118
+        if out is None:                                                     # :130-132
+            continue
+        res_d.append(out.res_d); J_d.append(out.J_d); res_m.append(out.res_m); J_m.append(out.J_m)
+        nv += out.n_valid; nk += out.n_keep
+    if not res_d:
+        return None
+    return torch.cat(res_d), torch.cat(J_d), torch.cat(res_m), torch.cat(J_m), nv, nk
+
+
+def shape_pose_joint_opt(dec: FoldedDecoder, opt_cfg, latent, T_ow, render_data, points_w, cube_radius,
+                         pose_known=False, faithful=False, trace: Optional[list] = None,
+                         solve64=False):
+    """Optimizer.shape_pose_joint_opt (optimizer.py:28-302).  Returns (latent, T_ow, iter_count).
+    `latent` is NOT mutated (the reference mutates in place, :248; its callers pass a clone)."""
+    o = opt_cfg
+    dt = dec.dtype
+    cv = o["converge"]
+    max_iter = int(cv["max_iter"])
+    eps_g, eps_c, eps_t, eps_r, eps_s = (float(cv[k]) for k in
+                                         ("epsilon_g", "epsilon_c", "epsilon_t", "epsilon_r", "epsilon_s"))
+    w_recon, w_depth, w_mask, w_code = (float(o["weight"][k]) for k in ("w_recon", "w_depth", "w_mask", "w_codereg"))
+    lm_on, lm_eye, lam0, s_damp = o["lm"]["lm_on"], o["lm"]["lm_eye"], float(o["lm"]["lm_lambda_0"]), float(o["lm"]["s_damp"])
+    t_recon, t_depth = float(o["recon"]["robust_th_m"]), float(o["render"]["robust_th_m"])
+    robust_iter = int(o["robust_iter"])
+    scale_on = bool(o["scale_on"])
+    P = 7 if scale_on else 6                                                # :55-58
+    latent = latent.detach().clone().to(dt)
+    T_ow = T_ow.detach().clone().to(dt)
+    L = latent.shape[0]
+    E = P + L
+    points_w = points_w.to(dt)
+    cur_scale = torch.det(T_ow[:3, :3]) ** (-1 / 3)                          # :66
+    F_all = len(render_data["T_wc"])
+    frame_ind = np.linspace(0, F_all - 1, min(int(o["render"]["n_frame"]), F_all)).astype(np.int32)  # :77-78
+    iter_count = 0
+    for i in range(max_iter):                                               # :88
+        rt = render_term(dec, latent, T_ow, render_data, frame_ind, cube_radius, cur_scale, o, scale_on)
+        if rt is None:                                                      # :139-141
+            break
+        res_d, J_d, res_m, J_m, nv, nk = rt
+        V = res_d.shape[0]
+        rho_d = huber(res_d, t_depth)[1] if i >= robust_iter else torch.ones_like(res_d)   # :145-149
+        H_d, b_d = _normal_eq(J_d, res_d, rho_d, w_depth, V, faithful)                     # :152-153
+        H_m, b_m = _normal_eq(J_m, res_m, torch.ones_like(res_m), w_mask, V, faithful)     # :158-159
+        pts_o = (points_w[..., None, :] * T_ow[:3, :3]).sum(-1) + T_ow[:3, 3]              # :168
+        r_s, Jp, Jc = compute_sdf_loss(dec, latent, pts_o, scale_on)                       # :170
+        J_s = torch.cat([Jp, Jc], dim=1)
+        rho_s = huber(r_s, t_recon)[1] if i >= robust_iter else torch.ones_like(r_s)       # :183-187
+        H_s, b_s = _normal_eq(J_s, r_s, rho_s, w_recon, r_s.shape[0], faithful)            # :189-190
+        H = torch.zeros(E, E, dtype=dt)
+        H += H_d; H += H_m; H += H_s                                                       # :210-213
+        H[P:, P:] += w_code * torch.eye(L, dtype=dt)                                       # :200-201
+        if scale_on:
+            H[P - 1, P - 1] += s_damp                                                      # :217-218
+        if lm_on:                                                                          # :220-225
+            if lm_eye:
+                H = H + lam0 * torch.max(torch.diag(H)) * torch.eye(E, dtype=dt)
+            else:
+                H = H + lam0 * torch.diag(torch.diag(H))
+        b = torch.zeros(E, dtype=dt)
+        b += b_d; b += b_m; b += b_s
+        b[P:] += -w_code * latent                                                          # :202-203
+        if solve64:
+            delta = torch.linalg.solve(H.double(), b.double()).to(dt)
+        else:
+            delta = torch.mv(torch.inverse(H), b)                                          # :234
+        if trace is not None:
+            trace.append(IterTrace(H.clone(), b.clone(), delta.clone(), nv, nk, V))
+        dp = delta[:P].clone()
+        if pose_known:
+            dp[:6] = 0                                                                     # :237-238
+        dc = delta[P:]
+        dT = exp_sim3(dp) if scale_on else exp_se3(dp)                                     # :242-245
+        T_ow = dT @ T_ow                                                                   # :247
+        latent = latent + dc                                                               # :248
+        cur_scale = torch.det(T_ow[:3, :3]) ** (-1 / 3)                                    # :250
+        d_scale = torch.det(dT[:3, :3]) ** (1 / 3)                                         # :251
+        d_tran = torch.linalg.vector_norm(dT[:3, 3]) * cur_scale                           # :252
+        d_rot = torch.abs(torch.acos((torch.trace(dT[:3, :3] * cur_scale) - 1) / 2)) * 180.0 / math.pi  # :253
+        iter_count = i + 1                                                                 # :273
+        if bool(torch.max(torch.abs(b)) < eps_g) and i > 1:                                # :276
+            break
+        if bool(torch.max(torch.abs(dc / (latent + 1e-12))) < eps_c) and i > 1:            # :280
+            break
+        if (not pose_known) and bool(d_tran < eps_t) and bool(d_rot < eps_r) and bool(d_scale < eps_s) and i > 1:  # :285
+            break
+    return latent, T_ow, iter_count
+
+
+def shape_opt_deepsdf(dec: FoldedDecoder, opt_cfg, latent, T_ow, points_w, faithful=False,
+                      trace: Optional[list] = None, solve64=False):
+    """Optimizer.shape_opt_deepsdf (optimizer.py:306-429): SDF term + code regulariser, pose frozen."""
+    o = opt_cfg
+    dt = dec.dtype
+    cv = o["converge"]
+    max_iter = int(cv["max_iter"])
+    eps_g, eps_c = float(cv["epsilon_g"]), float(cv["epsilon_c"])
+    w_recon, w_code = float(o["weight"]["w_recon"]), float(o["weight"]["w_codereg"])
+    lm_on, lm_eye, lam0 = o["lm"]["lm_on"], o["lm"]["lm_eye"], float(o["lm"]["lm_lambda_0"])
+    t_recon = float(o["recon"]["robust_th_m"])
+    robust_iter = int(o["robust_iter"])
+    scale_on = bool(o["scale_on"])
+    latent = latent.detach().clone().to(dt)
+    T_ow = T_ow.detach().clone().to(dt)
+    L = latent.shape[0]
+    points_w = points_w.to(dt)
+    iter_count = 0
+    for i in range(max_iter):                                               # :337
+        pts_o = (points_w[..., None, :] * T_ow[:3, :3]).sum(-1) + T_ow[:3, 3]   # :343
+        r_s, _, Jc = compute_sdf_loss(dec, latent, pts_o, scale_on)             # :345
+        rho = huber(r_s, t_recon)[1] if i >= robust_iter else torch.ones_like(r_s)   # :356-360
+        H, b = _normal_eq(Jc, r_s, rho, w_recon, r_s.shape[0], faithful)        # :362-363
+        H = H + w_code * torch.eye(L, dtype=dt)                                 # :371-372
+        b = b - w_code * latent                                                 # :373-374
+        if lm_on:                                                               # :385-390
+            if lm_eye:
+                H = H + lam0 * torch.max(torch.diag(H)) * torch.eye(L, dtype=dt)
+            else:
+                H = H + lam0 * torch.diag(torch.diag(H))
+        if solve64:
+            delta = torch.linalg.solve(H.double(), b.double()).to(dt)
+        else:
+            delta = torch.mv(torch.inverse(H), b)                               # :397
+        if trace is not None:
+            trace.append(IterTrace(H.clone(), b.clone(), delta.clone()))
+        latent = latent + delta                                                 # :401
+        iter_count = i + 1                                                      # :414
+        if bool(torch.max(torch.abs(b)) < eps_g) and i > 1:                     # :417
+            break
+        if bool(torch.max(torch.abs(delta / (latent + 1e-12))) < eps_c) and i > 1:   # :421
+            break
+    return latent, T_ow, iter_count
+
+
+# --------------------------------------------------------------------------------------
+# parity metric (metrics_3d/chamfer_distance.py:16-26): unsquared NN distances, mean both ways, halved
+# --------------------------------------------------------------------------------------
+def chamfer_distance(A: np.ndarray, B: np.ndarray) -> float:
+    from scipy.spatial import cKDTree
+    da = cKDTree(B).query(A)[0]
+    db = cKDTree(A).query(B)[0]
+    return 0.5 * (float(da.mean()) + float(db.mean()))

@@ -1,0 +1,57 @@
+"""Helpers shared by the golden-vector tests (pure data handling)."""
+import os
+
+import numpy as np
+import torch
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+# kwargs of hortimapping_amd.synthetic.make_synthetic_decoder for the decoders the fixtures were made with
+DEC_SPECS = {
+    "pepper32": dict(latent_dim=32, seed=1, r0=0.04, aniso=(1.0, 0.75, 1.3), wn_perturb=0.05),
+    "pepper256": dict(latent_dim=256, seed=2, r0=0.04, aniso=(1.0, 0.75, 1.3), wn_perturb=0.05),
+    "berry32": dict(latent_dim=32, seed=3, r0=0.02, aniso=(1.0, 1.2, 0.9), wn_perturb=0.0),
+}
+
+
+def load(name):
+    return np.load(os.path.join(GOLDEN_DIR, name + ".npz"), allow_pickle=False)
+
+
+def list_golden(prefix):
+    return sorted(f[:-4] for f in os.listdir(GOLDEN_DIR) if f.startswith(prefix) and f.endswith(".npz"))
+
+
+def decoder_params(name):
+    from hortimapping_amd import synthetic as S
+    return S.make_synthetic_decoder(**DEC_SPECS[str(name)])
+
+
+def cfg_from_golden(g):
+    """Rebuild the nested `opt` config dict from the flattened 'cfg.*' entries."""
+    o = {"lm": {}, "recon": {}, "render": {}, "weight": {}, "converge": {}}
+    for k in g.files:
+        if not k.startswith("cfg."):
+            continue
+        key = k[4:]
+        v = g[k].item()
+        if "." in key:
+            sec, kk = key.split(".")
+            o[sec][kk] = v
+        else:
+            o[key] = v
+    return o
+
+
+def render_data_from_golden(g, as_torch=True):
+    F = int(g["n_frames"])
+    rd = {}
+    for k in ("T_wc", "rays_fg", "rays_bg", "depth_fg", "depth_bg"):
+        rd[k] = [torch.from_numpy(g[f"{k}_{f}"]) if as_torch else g[f"{k}_{f}"] for f in range(F)]
+    return rd
+
+
+def relmax(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))

@@ -1,0 +1,149 @@
+"""CPU tests: the oracle (oracle/hm_oracle.py) against golden vectors captured from the reference's own code.
+
+This is the oracle's pin (the reference ships no tests of its own -- SURVEY.md 0.5/8c)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import hm_oracle as O
+from tests.golden_util import (cfg_from_golden, decoder_params, list_golden, load, relmax,
+                               render_data_from_golden)
+
+_DEC = {}
+
+
+def dec(name):
+    name = str(name)
+    if name not in _DEC:
+        _DEC[name] = O.fold_decoder(decoder_params(name))
+    return _DEC[name]
+
+
+@pytest.mark.parametrize("name", ["pepper32", "pepper256"])
+def test_g1_g2_decoder(name):
+    g = load(f"g12_decoder_{name}")
+    d = dec(name)
+    z, x = torch.from_numpy(g["z"]), torch.from_numpy(g["x"])
+    assert relmax(O.decoder_forward(d, z, x), g["sdf"]) < 2e-6
+    y, jac = O.decoder_jacobian(d, z, x)
+    assert relmax(y, g["y"]) < 2e-6
+    assert relmax(jac, g["g"]) < 5e-6
+    # fp64 oracle is the tie-breaker: fp32 reference and fp32 oracle are equally far from it
+    y64, j64 = O.decoder_jacobian(d.to(torch.float64), z, x)
+    assert relmax(g["g"], j64) < 5e-6 and relmax(jac, j64) < 5e-6
+
+
+def test_g3_pose_jacobians():
+    g = load("g3_pose_jac")
+    p = torch.from_numpy(g["pts"])
+    assert np.array_equal(O.pose_jacobian(p, False).numpy(), g["se3"])
+    assert np.array_equal(O.pose_jacobian(p, True).numpy(), g["sim3"])
+
+
+def test_g4_exp_maps():
+    g = load("g4_exp")
+    for i, v in enumerate(g["tangents"]):
+        v = torch.from_numpy(v)
+        assert np.allclose(O.exp_sim3(v).numpy(), g["sim3"][i], rtol=0, atol=1e-7), i
+        assert np.allclose(O.exp_se3(v[:6]).numpy(), g["se3"][i], rtol=0, atol=1e-7), i
+
+
+def test_g5_huber():
+    g = load("g5_huber")
+    rr, w2 = O.huber(torch.from_numpy(g["res"]), float(g["b"]))
+    assert np.allclose(rr.numpy(), g["robust_res"], rtol=1e-6, atol=1e-9)
+    assert np.allclose(w2.numpy(), g["w2"], rtol=1e-6, atol=1e-9)
+
+
+@pytest.mark.parametrize("name", ["pepper32", "pepper256"])
+def test_g6_sdf_loss(name):
+    g = load(f"g6_sdf_loss_{name}")
+    d = dec(name)
+    for sfx, so in (("sim3", True), ("se3", False)):
+        res, jp, jc = O.compute_sdf_loss(d, torch.from_numpy(g["z"]), torch.from_numpy(g["pts_o"]), so)
+        assert relmax(res, g[f"res_{sfx}"]) < 5e-6
+        assert relmax(jp, g[f"J_pose_{sfx}"]) < 5e-6
+        assert relmax(jc, g[f"J_code_{sfx}"]) < 5e-6
+
+
+@pytest.mark.parametrize("case", ["wild", "lab", "berry", "wild256"])
+def test_g7_render_loss(case):
+    g = load(f"g7_render_{case}")
+    d = dec(g["decoder"])
+    for f in range(int(g["n_frames"])):
+        out = O.compute_render_loss(d, torch.from_numpy(g["z"]), torch.from_numpy(g[f"rays_{f}"]),
+                                    torch.from_numpy(g[f"depth_fg_{f}"]), torch.from_numpy(g[f"depth_bg_{f}"]),
+                                    torch.from_numpy(g[f"T_oc_{f}"]), torch.from_numpy(g[f"sampled_depth_{f}"]),
+                                    bool(g["scale_on"]), bool(g["log_occ_on"]), float(g["occupancy_th"]),
+                                    float(g[f"bbx_radius_{f}"]), bool(g["occlusion_on"]))
+        assert out is not None
+        assert out.res_d.shape[0] == g[f"res_d_{f}"].shape[0]          # same rays emitted, same order
+        assert relmax(out.res_d, g[f"res_d_{f}"]) < 1e-5
+        assert relmax(out.res_m, g[f"res_m_{f}"]) < 1e-5
+        Jd = np.concatenate([g[f"J_d_pose_{f}"], g[f"J_d_code_{f}"]], axis=1)
+        Jm = np.concatenate([g[f"J_m_pose_{f}"], g[f"J_m_code_{f}"]], axis=1)
+        assert relmax(out.J_d, Jd) < 1e-5
+        assert relmax(out.J_m, Jm) < 1e-5
+
+
+def test_g7_render_none():
+    g = load("g7_render_none")
+    d = dec(g["decoder"])
+    out = O.compute_render_loss(d, torch.from_numpy(g["z"]), torch.from_numpy(g["rays_0"]),
+                                torch.from_numpy(g["depth_fg_0"]), torch.from_numpy(g["depth_bg_0"]),
+                                torch.from_numpy(g["T_oc_0"]), torch.from_numpy(g["sampled_depth_0"]),
+                                True, True, 0.01, float(g["bbx_radius_0"]), True)
+    assert out is None
+
+
+@pytest.mark.parametrize("name", ["pepper32", "pepper256"])
+def test_g8_one_iteration(name):
+    g = load(f"g8_one_iter_{name}")
+    d = dec(name)
+    cfg = cfg_from_golden(g)
+    rd = render_data_from_golden(g)
+    for faithful in (False, True):
+        tr = []
+        z, T, n = O.shape_pose_joint_opt(d, cfg, torch.from_numpy(g["z0"]), torch.from_numpy(g["T_ow0"]), rd,
+                                         torch.from_numpy(g["points_w"]), float(g["cube_radius"]),
+                                         pose_known=False, faithful=faithful, trace=tr)
+        assert relmax(tr[0].H, g["H_free"]) < 1e-5
+        assert relmax(tr[0].b, g["b_free"]) < 1e-5
+        assert relmax(tr[0].delta, g["delta_free"]) < 2e-4      # fp32 inverse of a cond~1e3 system
+        assert relmax(z, g["z_free"]) < 2e-4 and relmax(T, g["T_free"]) < 1e-5
+    tr = []
+    z, _, _ = O.shape_opt_deepsdf(d, cfg, torch.from_numpy(g["z0"]), torch.from_numpy(g["T_ow0"]),
+                                  torch.from_numpy(g["points_w"]), trace=tr)
+    assert relmax(tr[0].H, g["H_sdf"]) < 1e-5
+    assert relmax(tr[0].b, g["b_sdf"]) < 1e-5
+    assert relmax(tr[0].delta, g["delta_sdf"]) < 2e-4
+    assert relmax(z, g["z_sdf"]) < 2e-4
+
+
+def _run_traj(g):
+    d = dec(g["decoder"])
+    cfg = cfg_from_golden(g)
+    z0, T0, pw = torch.from_numpy(g["latent0"]), torch.from_numpy(g["T_ow0"]), torch.from_numpy(g["points_w"])
+    if str(g["kind"]) == "joint":
+        return O.shape_pose_joint_opt(d, cfg, z0, T0, render_data_from_golden(g), pw, float(g["cube_radius"]),
+                                      pose_known=bool(g["pose_known"]))
+    return O.shape_opt_deepsdf(d, cfg, z0, T0, pw)
+
+
+# state-level trajectory parity holds in the well-conditioned modes (shape-only, pose_known) and for the first
+# iterations of free-pose runs; long free-pose trajectories diverge at the 1e-2 level between ANY two fp32
+# evaluations of the reference itself (SURVEY.md 8d "parity noise floor"), so they get a loose bound.
+_TOL = {"free_sim3_it5": (0.2, 5e-3), "exit_grad_free": (0.5, 2e-2), "free_sim3_it2": (2e-3, 1e-4),
+        "free_se3_it2": (2e-3, 1e-4), "invalid_later": (2e-3, 1e-4)}
+
+
+@pytest.mark.parametrize("name", list_golden("g9_traj_"))
+def test_g9_trajectories(name):
+    g = load(name)
+    z, T, n = _run_traj(g)
+    tag = name[len("g9_traj_"):]
+    assert n == int(g["iter_count"]), (n, int(g["iter_count"]))
+    tz, tT = _TOL.get(tag, (1e-3, 1e-4))
+    if np.abs(g["z_out"]).max() > 0:
+        assert relmax(z, g["z_out"]) < tz
+    assert relmax(T, g["T_out"]) < tT
