@@ -1,0 +1,23 @@
+// C ABI of libhortihip.so (see include/hortimapping_amd.h for the contract of every entry point).
+#include "hm_common.h"
+#include "hm_internal.h"
+
+using namespace hm;
+
+extern "C" int hm_decode_batch(const hm_decoder_s* dec, int B, const float* d_latent, int ld_latent,
+                               const float* d_pts4, const int* d_nq, int n_stride, float* d_cbias,
+                               float* d_y, float* d_J, int ldJ, int pose_dim, int mode, void* stream) {
+  if (dec == nullptr || d_latent == nullptr || d_pts4 == nullptr || d_nq == nullptr || d_cbias == nullptr ||
+      d_y == nullptr) { hm_set_error("hm_decode_batch: null argument"); return -1; }
+  if (mode != 0 && mode != 1) { hm_set_error("hm_decode_batch: mode must be 0 or 1"); return -1; }
+  if (mode == 1 && (d_J == nullptr || ldJ < dec->L + POSE_PAD || (ldJ % 4) != 0)) {
+    hm_set_error("hm_decode_batch: Jacobian buffer needs ldJ >= L + %d and ldJ %% 4 == 0", POSE_PAD); return -1; }
+  if (pose_dim != 0 && pose_dim != 6 && pose_dim != 7) { hm_set_error("pose_dim must be 0, 6 or 7"); return -1; }
+  if (B <= 0) return 0;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  float* c0 = d_cbias;
+  float* c4 = d_cbias + (size_t)B * HID;
+  int rc = launch_latent_bias(dec, d_latent, ld_latent, nullptr, B, c0, c4, st);
+  if (rc) return rc;
+  return launch_decoder(dec, B, d_pts4, d_nq, nullptr, n_stride, c0, c4, d_y, d_J, ldJ, pose_dim, mode, st);
+}

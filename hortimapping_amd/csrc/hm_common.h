@@ -1,0 +1,69 @@
+// Shared device/host declarations of libhortihip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace hm {
+
+constexpr int HID = 512;        // hidden width of the DeepSDF decoder (specs.json:8)
+constexpr int TQ = 64;          // decoder queries per workgroup tile (2 MFMA N-blocks of 32)
+constexpr int NWAVE = 8;        // waves per decoder workgroup
+constexpr int NSTAGE = 16;      // 8 forward GEMM stages (lin0..lin7; lin8 is a VALU dot) + 8 backward
+constexpr int POSE_PAD = 8;     // pose columns reserved in a Jacobian row
+constexpr int MAX_L = 256;
+
+// epilogue kinds of a decoder stage
+enum {
+  EPI_FWD = 0,    // bias + ReLU, record mask, write activations
+  EPI_FWD3 = 1,   // lin3: as FWD, rows m..m+2 are overwritten with xyz (input of the skip layer)
+  EPI_FWD7 = 2,   // lin7: as FWD; followed by the lin8 dot + tanh
+  EPI_BWD = 3,    // multiply by ReLU mask of the producing layer, write gradients
+  EPI_BWD4 = 4,   // transpose of lin4: h3 part masked+written, latent part kept in registers
+  EPI_BWD0 = 5,   // transpose of lin0 (latent columns): accumulate onto the kept latent part, emit
+};
+
+struct StageDesc {
+  const float* wp;     // packed A operand: [(mb - mb_lo)][kg][64 lanes][4]
+  const float* bias;   // per-output bias (fwd) or nullptr; per-instance stages use c0/c4 instead
+  int n_kg;            // K groups of 8
+  int mb_lo, mb_hi;    // valid 32-row output blocks [lo, hi)
+  int epi;
+  int layer;           // forward layer whose mask is written (fwd) or read (bwd)
+  int inst_bias;       // 0: bias ptr, 1: c0[b], 2: c4[b]
+};
+
+struct DecoderDev {
+  int L, m, m_pad, mb_zx;        // m = 509 - L, m_pad = 512 - L, mb_zx = 16 - L/32
+  StageDesc st[NSTAGE];
+  const float* w8;               // [512]
+  float b8;
+  const float* w0x;              // [512][4]  xyz columns of lin0 (4th = 0)
+  const float* w4x;              // [512][4]  xyz columns of lin4
+  const float* w0z;              // [512][L]  latent columns of lin0 (row-major) for the per-instance bias
+  const float* w4z;              // [512][L]
+  const float* b0;               // [512]
+  const float* b4;               // [512]
+};
+
+}  // namespace hm
+
+struct hm_decoder_s {
+  hm::DecoderDev dev;
+  void* d_blob;        // one allocation holding every packed array
+  size_t blob_bytes;
+  int L;
+};
+
+#define HM_CHECK_HIP(expr)                                                        \
+  do {                                                                            \
+    hipError_t _e = (expr);                                                       \
+    if (_e != hipSuccess) {                                                       \
+      hm_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+      return -2;                                                                  \
+    }                                                                             \
+  } while (0)
+
+extern "C" void hm_set_error(const char* fmt, ...);

@@ -1,0 +1,163 @@
+// Host side of the decoder handle: weight ingest and packing into MFMA A-operand order.
+//
+// The reference rebuilds the decoder from specs.json + a state dict (deepsdf/deep_sdf/workspace.py:203-225,
+// deepsdf/networks/deep_sdf_decoder.py:29-72).  Here the caller passes the nine *folded* row-major fp32
+// matrices (weight-norm already applied: W = g * v / ||v||) and biases; we pre-pack each GEMM stage as
+// [row block of 32][K group of 8][lane 0..63][4] so that one global_load_dwordx4 per lane yields the A
+// operands of four consecutive v_mfma_f32_32x32x2_f32 (lane l: row l&31, k = 8*kg + 4*(l>>5) + j).
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <functional>
+#include <vector>
+
+#include "hm_common.h"
+
+using namespace hm;
+
+static thread_local char g_err[512] = "";
+
+extern "C" void hm_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+extern "C" const char* hm_last_error(void) { return g_err; }
+
+namespace {
+
+struct Blob {
+  std::vector<float> host;
+  size_t alloc(size_t n) {           // returns offset (in floats), 64-byte aligned
+    size_t off = (host.size() + 15) & ~size_t(15);
+    host.resize(off + n, 0.f);
+    return off;
+  }
+};
+
+// A(r, c) accessor -> packed [n_mb][n_kg][64][4]
+size_t pack_stage(Blob& blob, int mb_lo, int mb_hi, int n_kg, const std::function<float(int, int)>& A) {
+  const int n_mb = mb_hi - mb_lo;
+  size_t off = blob.alloc((size_t)n_mb * n_kg * 256);
+  for (int mbi = 0; mbi < n_mb; ++mbi)
+    for (int kg = 0; kg < n_kg; ++kg)
+      for (int lane = 0; lane < 64; ++lane)
+        for (int j = 0; j < 4; ++j) {
+          const int r = (mb_lo + mbi) * 32 + (lane & 31);
+          const int c = kg * 8 + (lane >> 5) * 4 + j;
+          blob.host[off + (((size_t)mbi * n_kg + kg) * 64 + lane) * 4 + j] = A(r, c);
+        }
+  return off;
+}
+
+}  // namespace
+
+extern "C" int hm_decoder_create(int latent_dim, const float* const* W, const float* const* bias,
+                                 hm_decoder_s** out) {
+  if (out == nullptr || W == nullptr || bias == nullptr) { hm_set_error("null argument"); return -1; }
+  const int L = latent_dim;
+  if (L < 32 || L > MAX_L || (L % 32) != 0) {
+    hm_set_error("latent_dim %d unsupported: need a multiple of 32 in [32, %d]", L, MAX_L);
+    return -1;
+  }
+  const int D0 = L + 3, m = HID - D0, m_pad = HID - L, mb_zx = 16 - L / 32;
+  // row-major shapes: W0 (512, D0), W1..2 (512,512), W3 (m,512), W4..7 (512,512), W8 (1,512)
+  auto w = [&](int l, int r, int c, int ld) { return W[l][(size_t)r * ld + c]; };
+
+  Blob blob;
+  struct Pending { size_t wp, bias; int has_bias; };
+  Pending pend[NSTAGE];
+  StageDesc st[NSTAGE];
+  memset(st, 0, sizeof(st));
+  auto set = [&](int s, int n_kg, int lo, int hi, int epi, int layer, int inst_bias,
+                 const std::function<float(int, int)>& A, const std::function<float(int)>* bfun) {
+    st[s].n_kg = n_kg; st[s].mb_lo = lo; st[s].mb_hi = hi; st[s].epi = epi; st[s].layer = layer;
+    st[s].inst_bias = inst_bias;
+    pend[s].wp = pack_stage(blob, lo, hi, n_kg, A);
+    pend[s].has_bias = 0;
+    if (bfun) {
+      pend[s].bias = blob.alloc(HID);
+      for (int f = 0; f < HID; ++f) blob.host[pend[s].bias + f] = (*bfun)(f);
+      pend[s].has_bias = 1;
+    }
+  };
+  auto plain_bias = [&](int l) { return std::function<float(int)>([=](int f) { return bias[l][f]; }); };
+
+  // ---- forward stages (deep_sdf_decoder.py:85-105) ----
+  set(0, 1, 0, 16, EPI_FWD, 0, 1, [&](int r, int c) { return c < 3 ? w(0, r, L + c, D0) : 0.f; }, nullptr);
+  { auto b1 = plain_bias(1); set(1, 64, 0, 16, EPI_FWD, 1, 0, [&](int r, int c) { return w(1, r, c, HID); }, &b1); }
+  { auto b2 = plain_bias(2); set(2, 64, 0, 16, EPI_FWD, 2, 0, [&](int r, int c) { return w(2, r, c, HID); }, &b2); }
+  { std::function<float(int)> b3 = [&](int f) { return f < m ? bias[3][f] : 0.f; };
+    set(3, 64, 0, m_pad / 32, EPI_FWD3, 3, 0, [&](int r, int c) { return r < m ? w(3, r, c, HID) : 0.f; }, &b3); }
+  // lin4 input is [h3 (m) | z (L) | xyz (3)] (:87-88); z is folded into c4, xyz sits in rows m..m+2 of X
+  set(4, m_pad / 8, 0, 16, EPI_FWD, 4, 2,
+      [&](int r, int c) { return c < m ? w(4, r, c, HID) : (c < m + 3 ? w(4, r, c + L, HID) : 0.f); }, nullptr);
+  for (int l = 5; l <= 7; ++l) {
+    auto bl = plain_bias(l);
+    set(l, 64, 0, 16, l == 7 ? EPI_FWD7 : EPI_FWD, l, 0, [&, l](int r, int c) { return w(l, r, c, HID); }, &bl);
+  }
+  // ---- backward stages: G_{l-1} = (G_l . mask_l) W_l  (utils.py:112-122 restated) ----
+  for (int i = 0; i < 3; ++i) {   // transposes of lin7, lin6, lin5 -> masks of lin6, lin5, lin4
+    const int l = 7 - i;
+    set(8 + i, 64, 0, 16, EPI_BWD, l - 1, 0, [&, l](int r, int c) { return w(l, c, r, HID); }, nullptr);
+  }
+  // transpose of lin4: rows [0,m) -> d/d h3 (mask of lin3), rows [m_pad, 512) -> d/d z
+  set(11, 64, 0, 16, EPI_BWD4, 3, 0,
+      [&](int r, int c) { return r < m ? w(4, c, r, HID) : (r < m_pad ? 0.f : w(4, c, m + (r - m_pad), HID)); },
+      nullptr);
+  set(12, m_pad / 8, 0, 16, EPI_BWD, 2, 0, [&](int r, int c) { return c < m ? w(3, c, r, HID) : 0.f; }, nullptr);
+  set(13, 64, 0, 16, EPI_BWD, 1, 0, [&](int r, int c) { return w(2, c, r, HID); }, nullptr);
+  set(14, 64, 0, 16, EPI_BWD, 0, 0, [&](int r, int c) { return w(1, c, r, HID); }, nullptr);
+  // transpose of lin0's latent columns, on the same (wave, slot) rows as lin4's latent rows
+  set(15, 64, mb_zx, 16, EPI_BWD0, 0, 0, [&](int r, int c) { return w(0, c, r - m_pad, D0); }, nullptr);
+
+  const size_t o_w8 = blob.alloc(HID), o_w0x = blob.alloc(HID * 4), o_w4x = blob.alloc(HID * 4);
+  const size_t o_w0z = blob.alloc((size_t)L * HID), o_w4z = blob.alloc((size_t)L * HID);
+  const size_t o_b0 = blob.alloc(HID), o_b4 = blob.alloc(HID);
+  for (int f = 0; f < HID; ++f) {
+    blob.host[o_w8 + f] = W[8][f];
+    for (int c = 0; c < 3; ++c) {
+      blob.host[o_w0x + f * 4 + c] = w(0, f, L + c, D0);
+      blob.host[o_w4x + f * 4 + c] = w(4, f, m + L + c, HID);
+    }
+    for (int j = 0; j < L; ++j) {
+      blob.host[o_w0z + (size_t)j * HID + f] = w(0, f, j, D0);
+      blob.host[o_w4z + (size_t)j * HID + f] = w(4, f, m + j, HID);
+    }
+    blob.host[o_b0 + f] = bias[0][f];
+    blob.host[o_b4 + f] = bias[4][f];
+  }
+
+  hm_decoder_s* d = new hm_decoder_s();
+  d->L = L;
+  d->blob_bytes = blob.host.size() * sizeof(float);
+  hipError_t e = hipMalloc(&d->d_blob, d->blob_bytes);
+  if (e != hipSuccess) { hm_set_error("hipMalloc(%zu) failed: %s", d->blob_bytes, hipGetErrorString(e)); delete d; return -2; }
+  e = hipMemcpy(d->d_blob, blob.host.data(), d->blob_bytes, hipMemcpyHostToDevice);
+  if (e != hipSuccess) { hm_set_error("hipMemcpy failed: %s", hipGetErrorString(e)); (void)hipFree(d->d_blob); delete d; return -2; }
+  const float* base = static_cast<const float*>(d->d_blob);
+  DecoderDev& dv = d->dev;
+  dv.L = L; dv.m = m; dv.m_pad = m_pad; dv.mb_zx = mb_zx;
+  for (int s = 0; s < NSTAGE; ++s) {
+    dv.st[s] = st[s];
+    dv.st[s].wp = base + pend[s].wp;
+    dv.st[s].bias = pend[s].has_bias ? base + pend[s].bias : nullptr;
+  }
+  dv.w8 = base + o_w8; dv.b8 = bias[8][0];
+  dv.w0x = base + o_w0x; dv.w4x = base + o_w4x; dv.w0z = base + o_w0z; dv.w4z = base + o_w4z;
+  dv.b0 = base + o_b0; dv.b4 = base + o_b4;
+  *out = d;
+  return 0;
+}
+
+extern "C" int hm_decoder_destroy(hm_decoder_s* d) {
+  if (d == nullptr) return 0;
+  (void)hipFree(d->d_blob);
+  delete d;
+  return 0;
+}
+
+extern "C" int hm_decoder_latent_dim(const hm_decoder_s* d) { return d ? d->L : -1; }
