@@ -114,6 +114,7 @@ __global__ __launch_bounds__(512, 2) void k_decoder(const DecodeArgs a) {
   f32x16 acc[2][2];
   f32x16 accz[2] = {zero16(), zero16()};
   float gx0 = 0.f, gx1 = 0.f, gx2 = 0.f;   // d sdf / d xyz partial (query = lane, rows of this wave)
+  float y_keep = 0.f;                      // sdf of query = lane (every wave computes the same value)
   const float* cbias0 = a.c0 + (size_t)b * HID;
   const float* cbias4 = a.c4 + (size_t)b * HID;
 
@@ -214,6 +215,7 @@ __global__ __launch_bounds__(512, 2) void k_decoder(const DecodeArgs a) {
         for (int i = 0; i < NWAVE; ++i) a8 += sc[i * 64 + lane];
         a8 += a.dec.b8;
         const float yv = tanhf(a8);
+        y_keep = yv;
         if (w == 0) {
           if (lane < cnt) a.y[qbase + lane] = yv;
           sc[2048 + lane] = 1.f - yv * yv;
@@ -307,6 +309,7 @@ __global__ __launch_bounds__(512, 2) void k_decoder(const DecodeArgs a) {
     }
     const f32x4 p = pts4[qbase + lane];
     float* row = a.J + (qbase + lane) * (size_t)a.ldJ + L;
+    row[7] = y_keep;                  // residual column of the extended row (consumed by K4)
     if (a.pose_dim == 0) {           // raw xyz gradient (get_batch_sdf_jacobian layout: [.., -3:])
       row[0] = g0; row[1] = g1; row[2] = g2;
     } else {

@@ -2,7 +2,86 @@
 #pragma once
 #include "hm_common.h"
 
+// per-instance status bits (mirrors include/hortimapping_amd.h)
+#define HM_STATUS_CONV_G 1        // optimizer.py:276  gradient convergence
+#define HM_STATUS_CONV_C 2        // optimizer.py:280  latent-code convergence
+#define HM_STATUS_CONV_P 4        // optimizer.py:285  pose convergence
+#define HM_STATUS_MAX_ITER 8      // optimizer.py:289
+#define HM_STATUS_INVALID 16      // optimizer.py:139-141 "This submap is not valid"
+#define HM_STATUS_SOLVE_FAILED 32 // non-finite / non-SPD system (the reference would propagate NaN)
+
 namespace hm {
+
+struct RowSegment {
+  const float* rows;       // base of the row buffer
+  size_t inst_stride;      // floats between instances
+  int row_offset;          // first row of the segment inside an instance's buffer
+  const int* count_dev;    // [B] rows in this segment (device) or nullptr -> count_const
+  int count_const;
+  const int* norm_dev;     // [B] normaliser n_t (device) or nullptr -> the row count
+  float weight;            // w_t
+  float robust_th;         // Huber threshold, <= 0: off
+};
+
+struct SolveArgs {
+  const float* Hext;       // [B][ldJ][ldJ]
+  float* latent;           // [B][ld_latent]
+  float* T_ow;             // [B][16]
+  const int* pose_known;   // [B] or nullptr
+  const int* V;            // [B] depth-render residual count (joint mode) or nullptr (shape-only)
+  int* active;             // [B]
+  int* iter_count;         // [B]
+  int* status;             // [B]
+  float* cur_scale;        // [B] or nullptr
+  float* dbg_A;            // [B][ldJ][ldJ] damped system (lower) or nullptr
+  float* dbg_b;            // [B][ldJ] or nullptr
+  float* dbg_delta;        // [B][ldJ] or nullptr
+  int L, P, ldJ, ld_latent;
+  int iter, max_iter;
+  int lm_on, lm_eye, scale_on;
+  float w_code, s_damp, lam0;
+  float eps_g, eps_c, eps_t, eps_r, eps_s;
+};
+
+struct RenderCfg {
+  int F, R, M;             // capacities: frames, rays per frame, samples per ray
+  int log_occ, occlusion_on, scale_on;
+  float occ_th, occlusion_th, min_grad;
+  int min_valid;
+};
+
+struct RenderBuffers {
+  // caller inputs
+  const float* T_wc;       // [B][F][16]
+  const float* rays;       // [B][F][R][3]  fg rays first, then bg
+  const float* depth;      // [B][F][R]
+  const int* n_fg;         // [B][F]
+  const int* n_bg;         // [B][F]
+  const int* n_frames;     // [B]
+  const float* cube_radius;// [B]
+  // workspace
+  float* frame;            // [B][F][16]  T_oc (12) | d_min | d_max | range | pad
+  int* valid_count;        // [B][F]
+  int* nRq;                // [B] samples to decode = n_frames * R * M
+  float* ptsR;             // [B][nR_stride][4]
+  float* sdfR;             // [B][nR_stride]
+  int* keepcnt;            // [B][F*R]
+  unsigned long long* keepmask;  // [B][F*R]
+  float* res_d;            // [B][F*R]
+  float* res_m;            // [B][F*R]
+  float* coef;             // [B][nR_stride][2]  (de_ds, dm_ds) per sample
+  int* ray_off;            // [B][F*R]
+  int* ray_row;            // [B][F*R]
+  int* nG;                 // [B] samples that need the Jacobian
+  int* V;                  // [B] emitted rays
+  float* ptsG;             // [B][nG_stride][4]
+  float* coefG;            // [B][nG_stride][2]
+  float* JG;               // [B][nG_stride][ldJ]
+  float* yG;               // [B][nG_stride]
+  float* JR;               // [B][2*F*R][ldJ]   depth rows then mask rows
+  int nR_stride, nG_stride;
+  int overflow_flag_unused;
+};
 
 int launch_latent_bias(const hm_decoder_s* dec, const float* d_latent, int ld_latent, const int* d_active,
                        int B, float* d_c0, float* d_c4, hipStream_t stream);
@@ -10,5 +89,20 @@ int launch_latent_bias(const hm_decoder_s* dec, const float* d_latent, int ld_la
 int launch_decoder(const hm_decoder_s* dec, int B, const float* d_pts, const int* d_nq, const int* d_active,
                    int n_stride, const float* d_c0, const float* d_c4, float* d_y, float* d_J, int ldJ,
                    int pose_dim, int mode, hipStream_t stream);
+
+int launch_normal_eq(const RowSegment* segs, int n_seg, int L, int B, const int* d_active, float* d_Hext,
+                     hipStream_t stream);
+
+int launch_solve_update(const SolveArgs& args, int B, hipStream_t stream);
+
+int launch_transform_points(const float* d_points_w, int n_in_stride, const int* d_n, const float* d_T_ow,
+                            const int* d_active, int B, int n_stride, float* d_pts4, hipStream_t stream);
+
+int launch_render_front(const RenderCfg& cfg, const RenderBuffers& rb, const float* d_T_ow, const int* d_active,
+                        int B, hipStream_t stream);          // frame setup + ray sampling
+int launch_render_scan(const RenderCfg& cfg, const RenderBuffers& rb, const int* d_active, int B,
+                       hipStream_t stream);                  // ray scan + offsets + scatter
+int launch_render_reduce(const RenderCfg& cfg, const RenderBuffers& rb, const int* d_active, int B, int L,
+                         hipStream_t stream);                // per-ray sum of sample Jacobians
 
 }  // namespace hm

@@ -1,0 +1,276 @@
+// Workspace + the batched Levenberg-Marquardt driver (the host side of the C ABI).
+//
+// `hm_optimize_batch` enqueues, per iteration and for all B instances at once, the kernel sequence that restates
+// one pass of the reference loop body (wild_completion/optimizer.py:88-291; shape-only variant :337-421):
+//   render term  (:93-159)  frame setup -> ray sampling -> K1 forward -> ray scan/offsets/scatter -> K1 fwd+bwd
+//                           -> per-ray reduce
+//   SDF term     (:163-190) point transform -> K1 fwd+bwd
+//   normal eqs   (:152-159,189-190,200-231) K4 (all terms in one pass) -> K5 (assemble, solve, update, converge)
+// There is no host<->device synchronisation inside the loop: per-instance `active` flags freeze finished
+// instances, and every data-dependent size (ball-valid samples, Jacobian samples, emitted rays) stays on the device.
+#include <string.h>
+
+#include <vector>
+
+#include "../../include/hortimapping_amd.h"
+#include "hm_common.h"
+#include "hm_internal.h"
+
+using namespace hm;
+
+struct hm_workspace_s {
+  hm_decoder_s* dec;
+  hm_limits lim;
+  int L, ldJ;
+  int nS_stride, nR_stride, nG_stride, nray;
+  void* d_blob;
+  size_t blob_bytes;
+  // device buffers
+  float *c0, *c4;
+  float *ptsS, *JS, *yS;
+  float* Hext;
+  int *active, *nS_dummy;
+  RenderBuffers rb;
+};
+
+namespace {
+
+struct Carver {
+  size_t off = 0;
+  char* base = nullptr;
+  template <typename T>
+  T* take(size_t n) {
+    off = (off + 255) & ~size_t(255);
+    T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
+    off += n * sizeof(T);
+    return p;
+  }
+};
+
+int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+void carve(hm_workspace_s* w, Carver& c) {
+  const int B = w->lim.max_batch, F = w->lim.max_frames, R = w->lim.max_rays;
+  const size_t nray = (size_t)F * R;
+  w->c0 = c.take<float>((size_t)B * HID);
+  w->c4 = c.take<float>((size_t)B * HID);
+  w->ptsS = c.take<float>((size_t)B * w->nS_stride * 4);
+  w->JS = c.take<float>((size_t)B * w->nS_stride * w->ldJ);
+  w->yS = c.take<float>((size_t)B * w->nS_stride);
+  w->Hext = c.take<float>((size_t)B * w->ldJ * w->ldJ);
+  w->active = c.take<int>(B);
+  RenderBuffers& rb = w->rb;
+  rb.frame = c.take<float>((size_t)B * F * 16);
+  rb.valid_count = c.take<int>((size_t)B * F);
+  rb.nRq = c.take<int>(B);
+  rb.ptsR = c.take<float>((size_t)B * w->nR_stride * 4);
+  rb.sdfR = c.take<float>((size_t)B * w->nR_stride);
+  rb.keepcnt = c.take<int>(B * nray);
+  rb.keepmask = c.take<unsigned long long>(B * nray);
+  rb.res_d = c.take<float>(B * nray);
+  rb.res_m = c.take<float>(B * nray);
+  rb.coef = c.take<float>((size_t)B * w->nR_stride * 2);
+  rb.ray_off = c.take<int>(B * nray);
+  rb.ray_row = c.take<int>(B * nray);
+  rb.nG = c.take<int>(B);
+  rb.V = c.take<int>(B);
+  rb.ptsG = c.take<float>((size_t)B * w->nG_stride * 4);
+  rb.coefG = c.take<float>((size_t)B * w->nG_stride * 2);
+  rb.JG = c.take<float>((size_t)B * w->nG_stride * w->ldJ);
+  rb.yG = c.take<float>((size_t)B * w->nG_stride);
+  rb.JR = c.take<float>((size_t)B * 2 * nray * w->ldJ);
+  rb.nR_stride = w->nR_stride;
+  rb.nG_stride = w->nG_stride;
+}
+
+__global__ void k_fill_int(int* p, int n, int v) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+
+__global__ void k_collect_counts(const RenderCfg cfg, const RenderBuffers rb, int B, int* out) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  int nv = 0;
+  for (int f = 0; f < cfg.F; ++f)
+    if (f < rb.n_frames[b] && rb.valid_count[b * cfg.F + f] >= cfg.min_valid) nv += rb.valid_count[b * cfg.F + f];
+  out[b * 4 + 0] = nv;
+  out[b * 4 + 1] = rb.nG[b];
+  out[b * 4 + 2] = rb.V[b];
+  out[b * 4 + 3] = 0;
+}
+
+int check_batch(const hm_workspace_s* ws, const hm_batch* bt, int mode) {
+  if (bt == nullptr) { hm_set_error("null batch"); return -1; }
+  if (bt->B <= 0 || bt->B > ws->lim.max_batch) { hm_set_error("batch size %d exceeds workspace limit %d", bt->B, ws->lim.max_batch); return -1; }
+  if (bt->d_points_w == nullptr || bt->d_n_points == nullptr || bt->d_latent == nullptr || bt->d_T_ow == nullptr ||
+      bt->d_iter_count == nullptr || bt->d_status == nullptr) { hm_set_error("null pointer in batch"); return -1; }
+  if (bt->points_stride <= 0) { hm_set_error("points_stride must be positive"); return -1; }
+  if (mode == 0 && (bt->d_T_wc == nullptr || bt->d_rays == nullptr || bt->d_depth == nullptr || bt->d_n_fg == nullptr ||
+                    bt->d_n_bg == nullptr || bt->d_n_frames == nullptr || bt->d_cube_radius == nullptr)) {
+    hm_set_error("render inputs missing for joint optimisation"); return -1; }
+  return 0;
+}
+
+RenderCfg make_render_cfg(const hm_workspace_s* ws, const hm_opt_cfg* cfg) {
+  RenderCfg rc;
+  rc.F = ws->lim.max_frames; rc.R = ws->lim.max_rays; rc.M = cfg->n_sample_on_ray;
+  rc.log_occ = cfg->log_sdf_occ; rc.occlusion_on = cfg->occlusion_on; rc.scale_on = cfg->scale_on;
+  rc.occ_th = cfg->occ_cutoff; rc.occlusion_th = cfg->occlusion_th; rc.min_grad = cfg->min_grad_thre;
+  rc.min_valid = cfg->min_valid_sample;
+  return rc;
+}
+
+void bind_inputs(RenderBuffers& rb, const hm_batch* bt) {
+  rb.T_wc = bt->d_T_wc; rb.rays = bt->d_rays; rb.depth = bt->d_depth; rb.n_fg = bt->d_n_fg; rb.n_bg = bt->d_n_bg;
+  rb.n_frames = bt->d_n_frames; rb.cube_radius = bt->d_cube_radius;
+}
+
+// render front end + Jacobian pass + per-ray reduce for the current state (optimizer.py:93-132)
+int render_pass(hm_workspace_s* ws, const RenderCfg& rc, const RenderBuffers& rb, const hm_batch* bt, int P,
+                const int* d_active, hipStream_t st) {
+  const int B = bt->B;
+  int rc_ = launch_render_front(rc, rb, bt->d_T_ow, d_active, B, st);
+  if (rc_) return rc_;
+  rc_ = launch_decoder(ws->dec, B, rb.ptsR, rb.nRq, d_active, ws->nR_stride, ws->c0, ws->c4, rb.sdfR, nullptr, 0, 0, 0, st);
+  if (rc_) return rc_;
+  rc_ = launch_render_scan(rc, rb, d_active, B, st);
+  if (rc_) return rc_;
+  rc_ = launch_decoder(ws->dec, B, rb.ptsG, rb.nG, d_active, ws->nG_stride, ws->c0, ws->c4, rb.yG, rb.JG, ws->ldJ, P, 1, st);
+  if (rc_) return rc_;
+  return launch_render_reduce(rc, rb, d_active, B, ws->L, st);
+}
+
+}  // namespace
+
+extern "C" int hm_workspace_create(hm_decoder_s* dec, const hm_limits* lim, hm_workspace_s** out) {
+  if (dec == nullptr || lim == nullptr || out == nullptr) { hm_set_error("null argument"); return -1; }
+  if (lim->max_batch <= 0 || lim->max_points <= 0 || lim->max_frames < 0 || lim->max_rays < 0 ||
+      lim->max_samples < 0 || lim->max_samples > 64 || lim->max_frames > 64) {
+    hm_set_error("bad limits (need batch>0, points>0, frames<=64, samples<=64)"); return -1; }
+  hm_workspace_s* w = new hm_workspace_s();
+  memset(w, 0, sizeof(*w));
+  w->dec = dec; w->lim = *lim; w->L = dec->L; w->ldJ = dec->L + POSE_PAD;
+  if (w->lim.max_frames == 0 || w->lim.max_rays == 0 || w->lim.max_samples == 0) {
+    w->lim.max_frames = 1; w->lim.max_rays = 1; w->lim.max_samples = 2;     // shape-only workspace
+  }
+  w->nray = w->lim.max_frames * w->lim.max_rays;
+  w->nS_stride = round_up(lim->max_points, TQ);
+  w->nR_stride = round_up(w->nray * w->lim.max_samples, TQ);
+  const int cap = lim->max_grad_samples > 0 ? lim->max_grad_samples : w->nray * w->lim.max_samples;
+  w->nG_stride = round_up(cap, TQ);
+  Carver size_pass;
+  carve(w, size_pass);
+  w->blob_bytes = size_pass.off + 256;
+  hipError_t e = hipMalloc(&w->d_blob, w->blob_bytes);
+  if (e != hipSuccess) { hm_set_error("hipMalloc(%zu) failed: %s", w->blob_bytes, hipGetErrorString(e)); delete w; return -2; }
+  e = hipMemset(w->d_blob, 0, w->blob_bytes);
+  if (e != hipSuccess) { hm_set_error("hipMemset failed: %s", hipGetErrorString(e)); (void)hipFree(w->d_blob); delete w; return -2; }
+  Carver c;
+  c.base = static_cast<char*>(w->d_blob);
+  carve(w, c);
+  *out = w;
+  return 0;
+}
+
+extern "C" int hm_workspace_destroy(hm_workspace_s* w) {
+  if (w == nullptr) return 0;
+  (void)hipFree(w->d_blob);
+  delete w;
+  return 0;
+}
+
+extern "C" size_t hm_workspace_bytes(hm_workspace_s* w) { return w ? w->blob_bytes : 0; }
+
+extern "C" int hm_optimize_batch(hm_workspace_s* ws, const hm_opt_cfg* cfg, const hm_batch* bt, int mode,
+                                 const hm_debug* dbg, void* stream) {
+  if (ws == nullptr || cfg == nullptr) { hm_set_error("null argument"); return -1; }
+  if (mode != 0 && mode != 1) { hm_set_error("mode must be 0 (joint) or 1 (shape only)"); return -1; }
+  int rc = check_batch(ws, bt, mode);
+  if (rc) return rc;
+  if (mode == 0 && (cfg->n_sample_on_ray < 2 || cfg->n_sample_on_ray > ws->lim.max_samples)) {
+    hm_set_error("n_sample_on_ray %d outside [2, %d]", cfg->n_sample_on_ray, ws->lim.max_samples); return -1; }
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int B = bt->B, L = ws->L;
+  const int P = mode == 1 ? 0 : (cfg->scale_on ? 7 : 6);
+
+  hipLaunchKernelGGL(k_fill_int, dim3((B + 255) / 256), dim3(256), 0, st, ws->active, B, 1);
+  hipLaunchKernelGGL(k_fill_int, dim3((B + 255) / 256), dim3(256), 0, st, bt->d_iter_count, B, 0);
+  hipLaunchKernelGGL(k_fill_int, dim3((B + 255) / 256), dim3(256), 0, st, bt->d_status, B, 0);
+  HM_CHECK_HIP(hipGetLastError());
+
+  RenderCfg rcfg = make_render_cfg(ws, cfg);
+  RenderBuffers rb = ws->rb;
+  if (mode == 0) bind_inputs(rb, bt);
+
+  for (int it = 0; it < cfg->max_iter; ++it) {
+    rc = launch_latent_bias(ws->dec, bt->d_latent, L, ws->active, B, ws->c0, ws->c4, st);
+    if (rc) return rc;
+    if (mode == 0) {
+      rc = render_pass(ws, rcfg, rb, bt, P, ws->active, st);
+      if (rc) return rc;
+    }
+    rc = launch_transform_points(bt->d_points_w, bt->points_stride, bt->d_n_points, bt->d_T_ow, ws->active, B,
+                                 ws->nS_stride, ws->ptsS, st);
+    if (rc) return rc;
+    rc = launch_decoder(ws->dec, B, ws->ptsS, bt->d_n_points, ws->active, ws->nS_stride, ws->c0, ws->c4, ws->yS,
+                        ws->JS, ws->ldJ, P == 0 ? 6 : P, 1, st);
+    if (rc) return rc;
+
+    const bool robust = it >= cfg->robust_iter;                             // optimizer.py:145,183
+    RowSegment segs[3];
+    segs[0] = RowSegment{ws->JS, (size_t)ws->nS_stride * ws->ldJ, 0, bt->d_n_points, 0, nullptr, cfg->w_recon,
+                         robust ? cfg->recon_robust_th : 0.f};
+    int n_seg = 1;
+    if (mode == 0) {
+      const size_t stride = (size_t)2 * ws->nray * ws->ldJ;
+      segs[1] = RowSegment{rb.JR, stride, 0, rb.V, 0, nullptr, cfg->w_depth, robust ? cfg->render_robust_th : 0.f};
+      segs[2] = RowSegment{rb.JR, stride, ws->nray, rb.V, 0, nullptr, cfg->w_mask, 0.f};   // mask never robust (:158)
+      n_seg = 3;
+    }
+    rc = launch_normal_eq(segs, n_seg, L, B, ws->active, ws->Hext, st);
+    if (rc) return rc;
+
+    SolveArgs sa;
+    memset(&sa, 0, sizeof(sa));
+    sa.Hext = ws->Hext; sa.latent = bt->d_latent; sa.T_ow = bt->d_T_ow;
+    sa.pose_known = bt->d_pose_known; sa.V = mode == 0 ? rb.V : nullptr;
+    sa.active = ws->active; sa.iter_count = bt->d_iter_count; sa.status = bt->d_status; sa.cur_scale = nullptr;
+    sa.dbg_A = dbg ? dbg->d_A : nullptr; sa.dbg_b = dbg ? dbg->d_b : nullptr; sa.dbg_delta = dbg ? dbg->d_delta : nullptr;
+    sa.L = L; sa.P = P; sa.ldJ = ws->ldJ; sa.ld_latent = L; sa.iter = it; sa.max_iter = cfg->max_iter;
+    sa.lm_on = cfg->lm_on; sa.lm_eye = cfg->lm_eye; sa.scale_on = cfg->scale_on;
+    sa.w_code = cfg->w_codereg; sa.s_damp = cfg->s_damp; sa.lam0 = cfg->lm_lambda_0;
+    sa.eps_g = cfg->epsilon_g; sa.eps_c = cfg->epsilon_c; sa.eps_t = cfg->epsilon_t; sa.eps_r = cfg->epsilon_r;
+    sa.eps_s = cfg->epsilon_s;
+    if (dbg && dbg->d_counts && mode == 0)
+      hipLaunchKernelGGL(k_collect_counts, dim3((B + 63) / 64), dim3(64), 0, st, rcfg, rb, B, dbg->d_counts);
+    rc = launch_solve_update(sa, B, st);
+    if (rc) return rc;
+  }
+  return 0;
+}
+
+extern "C" int hm_render_residuals(hm_workspace_s* ws, const hm_opt_cfg* cfg, const hm_batch* bt, float* d_rows,
+                                   int* d_V, int* d_ray_row, int* d_counts, void* stream) {
+  if (ws == nullptr || cfg == nullptr) { hm_set_error("null argument"); return -1; }
+  int rc = check_batch(ws, bt, 0);
+  if (rc) return rc;
+  if (cfg->n_sample_on_ray < 2 || cfg->n_sample_on_ray > ws->lim.max_samples) { hm_set_error("bad n_sample_on_ray"); return -1; }
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int B = bt->B, L = ws->L;
+  const int P = cfg->scale_on ? 7 : 6;
+  RenderCfg rcfg = make_render_cfg(ws, cfg);
+  RenderBuffers rb = ws->rb;
+  bind_inputs(rb, bt);
+  rc = launch_latent_bias(ws->dec, bt->d_latent, L, nullptr, B, ws->c0, ws->c4, st);
+  if (rc) return rc;
+  rc = render_pass(ws, rcfg, rb, bt, P, nullptr, st);
+  if (rc) return rc;
+  const size_t per_inst = (size_t)2 * ws->nray * ws->ldJ;
+  if (d_rows) HM_CHECK_HIP(hipMemcpyAsync(d_rows, rb.JR, per_inst * B * sizeof(float), hipMemcpyDeviceToDevice, st));
+  if (d_V) HM_CHECK_HIP(hipMemcpyAsync(d_V, rb.V, B * sizeof(int), hipMemcpyDeviceToDevice, st));
+  if (d_ray_row) HM_CHECK_HIP(hipMemcpyAsync(d_ray_row, rb.ray_row, (size_t)B * ws->nray * sizeof(int), hipMemcpyDeviceToDevice, st));
+  if (d_counts) hipLaunchKernelGGL(k_collect_counts, dim3((B + 63) / 64), dim3(64), 0, st, rcfg, rb, B, d_counts);
+  HM_CHECK_HIP(hipGetLastError());
+  return 0;
+}

@@ -1,0 +1,147 @@
+/* libhortihip.so -- C ABI of the MI355X-native HortiMapping hot path.
+ *
+ * The reference (PRBonn/HortiMapping @ 2024_08_07) is pure Python; its operator interface for this path is
+ *     Optimizer(cfg, decoder, mesher, vis).shape_pose_joint_opt(latent, T_ow, render_data, points_w, cube_radius,
+ *                                                              cur_color, pose_known) -> (latent, T_ow, iter_count)
+ *     Optimizer.shape_opt_deepsdf(latent, T_ow, points_w, cur_color)                 -> (latent, T_ow, iter_count)
+ * (wild_completion/optimizer.py:17,28,302,306,429) plus the functional helpers decode_sdf / get_batch_sdf_jacobian
+ * (wild_completion/utils.py:144,175) and compute_sdf_loss / compute_render_loss (wild_completion/loss.py:8,219).
+ * Each entry point below names the reference interface it replaces.  Conventions:
+ *   - every function returns 0 on success, < 0 on error (never throws); hm_last_error() describes the failure;
+ *   - all `d_*` pointers are device (HBM) pointers owned by the caller; the library never frees caller memory;
+ *   - work is enqueued on the caller's hipStream_t (passed as void*); nothing synchronises the host unless stated;
+ *   - matrices are row-major fp32; index arrays are int32.
+ */
+#ifndef HORTIMAPPING_AMD_H
+#define HORTIMAPPING_AMD_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct hm_decoder_s* hm_decoder_t;
+typedef struct hm_workspace_s* hm_workspace_t;
+
+/* per-instance status bits written by hm_optimize_batch */
+#define HM_STATUS_CONV_G 1        /* optimizer.py:276  '**** Convergence in gradient ****'          */
+#define HM_STATUS_CONV_C 2        /* optimizer.py:280  '**** Convergence in Shape Latent Code ****' */
+#define HM_STATUS_CONV_P 4        /* optimizer.py:285  '**** Convergence in Pose Parameters ****'   */
+#define HM_STATUS_MAX_ITER 8      /* optimizer.py:289  maximum iteration number                      */
+#define HM_STATUS_INVALID 16      /* optimizer.py:139-141 'This submap is not valid' (no depth residual left) */
+#define HM_STATUS_SOLVE_FAILED 32 /* normal matrix not positive definite / non-finite step             */
+
+const char* hm_last_error(void);
+
+/* ---- decoder handle: replaces config_decoder (deepsdf/deep_sdf/workspace.py:203-225) + Decoder.__init__
+ * (deepsdf/networks/deep_sdf_decoder.py:11-72).  W[l], bias[l] (l = 0..8) are HOST pointers to the folded
+ * (weight-norm applied) row-major fp32 matrices: W0 (512, L+3), W1..2 (512,512), W3 (509-L, 512), W4..7 (512,512),
+ * W8 (1,512).  Only the shipped architecture (8 x 512, latent_in=[4]) with L a multiple of 32, 32 <= L <= 256. */
+int hm_decoder_create(int latent_dim, const float* const* W, const float* const* bias, hm_decoder_t* out);
+int hm_decoder_destroy(hm_decoder_t dec);
+int hm_decoder_latent_dim(hm_decoder_t dec);
+
+/* ---- functional parity hooks.
+ * mode 0 replaces decode_sdf (wild_completion/utils.py:144-172): d_y[b][i] = sdf(latent_b, pts_b_i).
+ * mode 1 replaces get_batch_sdf_jacobian (utils.py:175-193) and the chain rule of compute_sdf_loss
+ * (wild_completion/loss.py:219-243): besides d_y, row i of d_J (ldJ >= L+8 floats, ldJ % 4 == 0) receives
+ *   [ d sdf/d z (L) | pose part (pose_dim) | .. | sdf ] with the pose part = d sdf/d xyz (3) for pose_dim 0,
+ *   d sdf/d xyz . [I | -[p]x] for pose_dim 6 (SE3), ... | p] for pose_dim 7 (Sim3); column L+7 holds sdf.
+ * d_pts4: [B][n_stride][4] object-frame points (xyz, w ignored), n_stride % 64 == 0; d_nq[b] = valid points;
+ * d_cbias: scratch of 2*B*512 floats. */
+int hm_decode_batch(hm_decoder_t dec, int B, const float* d_latent, int ld_latent, const float* d_pts4,
+                    const int* d_nq, int n_stride, float* d_cbias, float* d_y, float* d_J, int ldJ,
+                    int pose_dim, int mode, void* stream);
+
+/* ---- optimiser.  All keys of the reference's `opt:` YAML block (configs/wild_pepper.yaml:19-57) plus the
+ * hidden constants of compute_render_loss (wild_completion/loss.py:11) and the optimiser's depth window
+ * (wild_completion/optimizer.py:110). */
+typedef struct hm_opt_cfg {
+  int scale_on;            /* opt.scale_on: Sim(3) (7 dof) or SE(3) (6 dof)                    */
+  int robust_iter;         /* opt.robust_iter                                                   */
+  int lm_on, lm_eye;       /* opt.lm.lm_on / lm_eye                                             */
+  float lm_lambda_0;       /* opt.lm.lm_lambda_0                                                */
+  float s_damp;            /* opt.lm.s_damp                                                     */
+  float recon_robust_th;   /* opt.recon.robust_th_m                                             */
+  float render_robust_th;  /* opt.render.robust_th_m                                            */
+  int n_sample_on_ray;     /* opt.render.n_sample_on_ray (<= 64)                                */
+  int log_sdf_occ;         /* opt.render.log_sdf_occ                                            */
+  float occ_cutoff;        /* opt.render.occ_cutoff_m                                           */
+  int occlusion_on;        /* opt.render.occlusion_on                                           */
+  float w_recon, w_depth, w_mask, w_codereg;          /* opt.weight.*                           */
+  int max_iter;            /* opt.converge.max_iter                                             */
+  float epsilon_g, epsilon_c, epsilon_t, epsilon_r, epsilon_s;   /* opt.converge.*              */
+  float occlusion_th;      /* loss.py:11 occlusion_th = 0.03                                    */
+  int min_valid_sample;    /* loss.py:11 min_valid_sample = 100                                 */
+  float min_grad_thre;     /* loss.py:11 min_grad_thre = 1e-6                                   */
+} hm_opt_cfg;
+
+typedef struct hm_limits {
+  int max_batch;           /* instances per call                                                */
+  int max_points;          /* surface points per instance                                       */
+  int max_frames;          /* rendered frames per instance (opt.render.n_frame)                 */
+  int max_rays;            /* fg + bg rays per frame                                            */
+  int max_samples;         /* samples per ray                                                   */
+  int max_grad_samples;    /* Jacobian samples per instance in the render term; 0 = frames*rays*samples */
+} hm_limits;
+
+/* One batch of independent fruit instances, everything device resident.  Field <-> reference argument:
+ *   points_w     [B][points_stride][3]  `points_w_torch` (optimizer.py:28), n_points[b] valid rows
+ *   T_wc         [B][max_frames][16]    render_data["T_wc"][sample_frame_ind] (optimizer.py:77-79,103)
+ *   rays         [B][max_frames][max_rays][3]  cat(rays_fg, rays_bg) per frame (optimizer.py:113)
+ *   depth        [B][max_frames][max_rays]     cat(depth_fg, depth_bg) per frame (loss.py:26)
+ *   n_fg, n_bg   [B][max_frames]        ray counts per frame;  n_frames [B]
+ *   latent       [B][L]   in: initial code, out: optimised code (the reference mutates `latent` in place, :248)
+ *   T_ow         [B][16]  in: initial object<-world Sim(3), out: optimised
+ *   cube_radius  [B]      `cube_radius` (optimizer.py:28);  pose_known [B] (0/1)
+ *   iter_count, status [B] outputs.  Instance order is preserved (result b belongs to input b). */
+typedef struct hm_batch {
+  int B;
+  int points_stride;
+  const float* d_points_w;
+  const int* d_n_points;
+  const float* d_T_wc;
+  const float* d_rays;
+  const float* d_depth;
+  const int* d_n_fg;
+  const int* d_n_bg;
+  const int* d_n_frames;
+  const float* d_cube_radius;
+  const int* d_pose_known;
+  float* d_latent;
+  float* d_T_ow;
+  int* d_iter_count;
+  int* d_status;
+} hm_batch;
+
+/* optional per-iteration debug capture (single-iteration parity tests): damped normal matrix (lower triangle,
+ * unknown order [z | pose], leading dimension L+8), right-hand side b and step delta of the LAST executed iteration */
+typedef struct hm_debug {
+  float* d_A;      /* [B][L+8][L+8] or NULL */
+  float* d_b;      /* [B][L+8] or NULL      */
+  float* d_delta;  /* [B][L+8] or NULL      */
+  int* d_counts;   /* [B][4]: ball-valid samples, Jacobian samples, emitted rays, 0  (last iteration) or NULL */
+} hm_debug;
+
+int hm_workspace_create(hm_decoder_t dec, const hm_limits* limits, hm_workspace_t* out);
+int hm_workspace_destroy(hm_workspace_t ws);
+size_t hm_workspace_bytes(hm_workspace_t ws);
+
+/* Replaces Optimizer.shape_pose_joint_opt (mode 0; optimizer.py:28-302) and Optimizer.shape_opt_deepsdf (mode 1;
+ * optimizer.py:306-429) for a whole batch.  Enqueues cfg->max_iter iterations on `stream` with no host sync;
+ * instances that converge / become invalid are frozen bit-exactly by device-side flags. */
+int hm_optimize_batch(hm_workspace_t ws, const hm_opt_cfg* cfg, const hm_batch* batch, int mode,
+                      const hm_debug* dbg, void* stream);
+
+/* Replaces one call of compute_render_loss per frame (wild_completion/loss.py:8-217) for a batch: runs the render
+ * front end + Jacobian pass for the current (latent, T_ow) and leaves, per instance, V[b] depth rows followed (at row
+ * offset max_frames*max_rays) by V[b] mask rows of L+8 floats [d res/d z | d res/d pose | res] in d_rows
+ * ([B][2*max_frames*max_rays][L+8]); d_V[b] = emitted rays, d_ray_row[b][ray] = row of that ray or -1. */
+int hm_render_residuals(hm_workspace_t ws, const hm_opt_cfg* cfg, const hm_batch* batch, float* d_rows,
+                        int* d_V, int* d_ray_row, int* d_counts, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
