@@ -40,6 +40,9 @@ def lib():
             raise HortiHipError(
                 f"{LIB_PATH} not found: build it with `python -m hortimapping_amd.build` "
                 "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+        # torch bundles its own libamdhip64.so.7 / libhsa-runtime64; load it FIRST so that libhortihip.so binds to the
+        # same HIP runtime instance (two runtimes in one process cannot share device pointers or streams)
+        import torch  # noqa: F401
         _lib = ctypes.CDLL(LIB_PATH)
         _declare(_lib)
     return _lib

@@ -31,6 +31,7 @@ struct DecodeArgs {
   float* y;            // [B][n_stride] sdf
   float* J;            // [B][n_stride][ldJ] rows [d sdf/d z (L) | d sdf/d pose (P) | pad]
   int n_stride;
+  int B;
   int ldJ;
   int pose_dim;        // 0 (shape only), 6 (SE3), 7 (Sim3)
   int mode;            // 0 forward only, 1 forward + backward
@@ -78,6 +79,10 @@ __device__ __forceinline__ void gemm_loop(f32x16 (&acc)[2][2], const f32x4* __re
   case 0: OP(mk0); break; case 1: OP(mk1); break; case 2: OP(mk2); break; case 3: OP(mk3); break; \
   case 4: OP(mk4); break; case 5: OP(mk5); break; case 6: OP(mk6); break; default: OP(mk7); break;
 
+// MODE 0: forward only (decode_sdf).  MODE 1: forward + input-gradient backward.  TAG only gives the two
+// fwd+bwd call sites of an LM iteration (0: SDF-term rows, 1: render-term samples) distinct kernel names so that
+// rocprofv3 --stats reports them separately; the code is identical.
+template <int MODE, int TAG>
 __global__ __launch_bounds__(512, 2) void k_decoder(const DecodeArgs a) {
   __shared__ f32x4 xs[128 * TQ];   // 128 KiB: X[k/4][q] as float4 over k%4
   __shared__ float sc[2048 + 128]; // partial sums of the VALU side paths
@@ -85,9 +90,11 @@ __global__ __launch_bounds__(512, 2) void k_decoder(const DecodeArgs a) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int tiles_per_inst = a.n_stride / TQ;
-  const int b = blockIdx.x / tiles_per_inst;
-  const int q0 = (blockIdx.x % tiles_per_inst) * TQ;
+  // tile-major block order: blockIdx = tile * B + b.  Real tiles of a ragged launch (render samples: a few tiles
+  // per instance, the rest of the capacity empty) are then contiguous in blockIdx and spread round-robin over all
+  // 8 XCDs; instance-major order put them all on XCDs 0..2 (block i runs on XCD i % 8) and quadrupled the launch time.
+  const int b = blockIdx.x % a.B;
+  const int q0 = (blockIdx.x / a.B) * TQ;
   if (a.active != nullptr && a.active[b] == 0) return;
   const int nq = a.n_q[b];
   if (q0 >= nq) return;
@@ -118,7 +125,8 @@ __global__ __launch_bounds__(512, 2) void k_decoder(const DecodeArgs a) {
   const float* cbias0 = a.c0 + (size_t)b * HID;
   const float* cbias4 = a.c4 + (size_t)b * HID;
 
-  for (int s = 0; s < NSTAGE; ++s) {
+  constexpr int n_stage = MODE == 0 ? 8 : NSTAGE;
+  for (int s = 0; s < n_stage; ++s) {
     const StageDesc& sd = a.dec.st[s];
     const int epi = sd.epi;
     const int mb0 = w, mb1 = w + 8;
@@ -126,7 +134,7 @@ __global__ __launch_bounds__(512, 2) void k_decoder(const DecodeArgs a) {
     const bool u1 = (mb1 >= sd.mb_lo) && (mb1 < sd.mb_hi);
     __syncthreads();   // X of this stage complete
 
-    if (epi == EPI_BWD4 || epi == EPI_BWD0) {
+    if (MODE == 1 && (epi == EPI_BWD4 || epi == EPI_BWD0)) {
       // xyz columns of lin4 / lin0, transposed: 3 x 512 dot per query on the VALU (rows of this wave's K slice)
       const f32x4* wx = reinterpret_cast<const f32x4*>(epi == EPI_BWD4 ? a.dec.w4x : a.dec.w0x);
 #pragma unroll 4
@@ -143,7 +151,7 @@ __global__ __launch_bounds__(512, 2) void k_decoder(const DecodeArgs a) {
     }
 
     acc[0][0] = zero16(); acc[0][1] = zero16();
-    if (epi == EPI_BWD0) { acc[1][0] = accz[0]; acc[1][1] = accz[1]; }
+    if (MODE == 1 && epi == EPI_BWD0) { acc[1][0] = accz[0]; acc[1][1] = accz[1]; }
     else { acc[1][0] = zero16(); acc[1][1] = zero16(); }
 
     {
@@ -156,7 +164,7 @@ __global__ __launch_bounds__(512, 2) void k_decoder(const DecodeArgs a) {
     }
     __syncthreads();   // every wave is done reading X
 
-    if (epi <= EPI_FWD7) {
+    if (MODE == 0 || epi <= EPI_FWD7) {
       const float* bias = sd.inst_bias == 1 ? cbias0 : (sd.inst_bias == 2 ? cbias4 : sd.bias);
       uint2 mk = {0, 0};
 #pragma unroll
@@ -193,7 +201,7 @@ __global__ __launch_bounds__(512, 2) void k_decoder(const DecodeArgs a) {
         if (sl == 0) mk.x = bits; else mk.y = bits;
       }
 #define HM_SET(M) M = mk
-      switch (sd.layer) { HM_MASK_CASES(HM_SET) }
+      if (MODE == 1) switch (sd.layer) { HM_MASK_CASES(HM_SET) }
 #undef HM_SET
 
       if (epi == EPI_FWD7) {
@@ -220,7 +228,7 @@ __global__ __launch_bounds__(512, 2) void k_decoder(const DecodeArgs a) {
           if (lane < cnt) a.y[qbase + lane] = yv;
           sc[2048 + lane] = 1.f - yv * yv;
         }
-        if (a.mode == 0) return;
+        if (MODE == 0) return;
         __syncthreads();
         const float dyA = sc[2048 + qa], dyB = sc[2048 + 32 + qa];
         // seed of the backward pass: G7 = (1 - y^2) * W8, masked by lin7's ReLU mask
@@ -244,7 +252,7 @@ __global__ __launch_bounds__(512, 2) void k_decoder(const DecodeArgs a) {
           }
         }
       }
-    } else if (epi == EPI_BWD || epi == EPI_BWD4) {
+    } else if (MODE == 1 && (epi == EPI_BWD || epi == EPI_BWD4)) {
       uint2 mk;
 #define HM_GET(M) mk = M
       switch (sd.layer) { HM_MASK_CASES(HM_GET) }
@@ -272,7 +280,7 @@ __global__ __launch_bounds__(512, 2) void k_decoder(const DecodeArgs a) {
           }
         }
       }
-    } else {  // EPI_BWD0: d sdf / d z complete for this wave's latent rows
+    } else if (MODE == 1) {  // EPI_BWD0: d sdf / d z complete for this wave's latent rows
       if (u1) {
         const int jz = (mb1 - mb_zx) * 32;
 #pragma unroll
@@ -293,6 +301,7 @@ __global__ __launch_bounds__(512, 2) void k_decoder(const DecodeArgs a) {
     }
   }
 
+  if (MODE == 0) return;
   // d sdf / d xyz: reduce the 8 per-wave partials, then the pose chain rule
   //   J_pose = g_x [ I | -[p]x | p ]   (loss.py:236-239, utils.py:197-217,257-276)
   sc[(w * 4 + 0) * 64 + lane] = gx0;
@@ -354,15 +363,17 @@ int launch_latent_bias(const hm_decoder_s* dec, const float* d_latent, int ld_la
 
 int launch_decoder(const hm_decoder_s* dec, int B, const float* d_pts, const int* d_nq, const int* d_active,
                    int n_stride, const float* d_c0, const float* d_c4, float* d_y, float* d_J, int ldJ,
-                   int pose_dim, int mode, hipStream_t stream) {
+                   int pose_dim, int mode, hipStream_t stream, int tag) {
   if (n_stride % TQ != 0) { hm_set_error("n_stride must be a multiple of %d", TQ); return -1; }
   DecodeArgs a;
   a.dec = dec->dev;
   a.pts = d_pts; a.n_q = d_nq; a.active = d_active; a.c0 = d_c0; a.c4 = d_c4;
-  a.y = d_y; a.J = d_J; a.n_stride = n_stride; a.ldJ = ldJ; a.pose_dim = pose_dim; a.mode = mode;
+  a.y = d_y; a.J = d_J; a.n_stride = n_stride; a.B = B; a.ldJ = ldJ; a.pose_dim = pose_dim; a.mode = mode;
   const int grid = B * (n_stride / TQ);
   if (grid == 0) return 0;
-  hipLaunchKernelGGL(k_decoder, dim3(grid), dim3(512), 0, stream, a);
+  if (mode == 0) hipLaunchKernelGGL((k_decoder<0, 0>), dim3(grid), dim3(512), 0, stream, a);
+  else if (tag == 0) hipLaunchKernelGGL((k_decoder<1, 0>), dim3(grid), dim3(512), 0, stream, a);
+  else hipLaunchKernelGGL((k_decoder<1, 1>), dim3(grid), dim3(512), 0, stream, a);
   HM_CHECK_HIP(hipGetLastError());
   return 0;
 }

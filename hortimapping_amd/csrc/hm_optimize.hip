@@ -31,6 +31,10 @@ struct hm_workspace_s {
   float* Hext;
   int *active, *nS_dummy;
   RenderBuffers rb;
+  // optional timing of the dominant launch (SDF-term K1) with HIP events on the caller's stream
+  int profile_on;
+  std::vector<hipEvent_t> ev;     // pairs (start, stop)
+  size_t ev_used;
 };
 
 namespace {
@@ -136,7 +140,7 @@ int render_pass(hm_workspace_s* ws, const RenderCfg& rc, const RenderBuffers& rb
   if (rc_) return rc_;
   rc_ = launch_render_scan(rc, rb, d_active, B, st);
   if (rc_) return rc_;
-  rc_ = launch_decoder(ws->dec, B, rb.ptsG, rb.nG, d_active, ws->nG_stride, ws->c0, ws->c4, rb.yG, rb.JG, ws->ldJ, P, 1, st);
+  rc_ = launch_decoder(ws->dec, B, rb.ptsG, rb.nG, d_active, ws->nG_stride, ws->c0, ws->c4, rb.yG, rb.JG, ws->ldJ, P, 1, st, 1);
   if (rc_) return rc_;
   return launch_render_reduce(rc, rb, d_active, B, ws->L, st);
 }
@@ -149,7 +153,7 @@ extern "C" int hm_workspace_create(hm_decoder_s* dec, const hm_limits* lim, hm_w
       lim->max_samples < 0 || lim->max_samples > 64 || lim->max_frames > 64) {
     hm_set_error("bad limits (need batch>0, points>0, frames<=64, samples<=64)"); return -1; }
   hm_workspace_s* w = new hm_workspace_s();
-  memset(w, 0, sizeof(*w));
+  w->profile_on = 0; w->ev_used = 0; w->d_blob = nullptr; w->blob_bytes = 0; w->nS_dummy = nullptr;
   w->dec = dec; w->lim = *lim; w->L = dec->L; w->ldJ = dec->L + POSE_PAD;
   if (w->lim.max_frames == 0 || w->lim.max_rays == 0 || w->lim.max_samples == 0) {
     w->lim.max_frames = 1; w->lim.max_rays = 1; w->lim.max_samples = 2;     // shape-only workspace
@@ -173,8 +177,31 @@ extern "C" int hm_workspace_create(hm_decoder_s* dec, const hm_limits* lim, hm_w
   return 0;
 }
 
+extern "C" int hm_workspace_profile(hm_workspace_s* w, int enable) {
+  if (w == nullptr) { hm_set_error("null workspace"); return -1; }
+  w->profile_on = enable;
+  w->ev_used = 0;
+  return 0;
+}
+
+// Sum of the HIP-event durations of the SDF-term K1 launches recorded since profiling was (re)enabled.
+// The caller must have synchronised the stream.
+extern "C" int hm_workspace_profile_read(hm_workspace_s* w, double* ms_total, long long* launches) {
+  if (w == nullptr || ms_total == nullptr || launches == nullptr) { hm_set_error("null argument"); return -1; }
+  double tot = 0.0;
+  for (size_t i = 0; i + 1 < w->ev_used; i += 2) {
+    float ms = 0.f;
+    HM_CHECK_HIP(hipEventElapsedTime(&ms, w->ev[i], w->ev[i + 1]));
+    tot += ms;
+  }
+  *ms_total = tot;
+  *launches = (long long)(w->ev_used / 2);
+  return 0;
+}
+
 extern "C" int hm_workspace_destroy(hm_workspace_s* w) {
   if (w == nullptr) return 0;
+  for (hipEvent_t e : w->ev) (void)hipEventDestroy(e);
   (void)hipFree(w->d_blob);
   delete w;
   return 0;
@@ -213,9 +240,21 @@ extern "C" int hm_optimize_batch(hm_workspace_s* ws, const hm_opt_cfg* cfg, cons
     rc = launch_transform_points(bt->d_points_w, bt->points_stride, bt->d_n_points, bt->d_T_ow, ws->active, B,
                                  ws->nS_stride, ws->ptsS, st);
     if (rc) return rc;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    if (ws->profile_on) {
+      while (ws->ev.size() < ws->ev_used + 2) {
+        hipEvent_t e;
+        HM_CHECK_HIP(hipEventCreate(&e));
+        ws->ev.push_back(e);
+      }
+      ev0 = ws->ev[ws->ev_used]; ev1 = ws->ev[ws->ev_used + 1];
+      ws->ev_used += 2;
+      HM_CHECK_HIP(hipEventRecord(ev0, st));
+    }
     rc = launch_decoder(ws->dec, B, ws->ptsS, bt->d_n_points, ws->active, ws->nS_stride, ws->c0, ws->c4, ws->yS,
-                        ws->JS, ws->ldJ, P == 0 ? 6 : P, 1, st);
+                        ws->JS, ws->ldJ, P == 0 ? 6 : P, 1, st, 0);
     if (rc) return rc;
+    if (ev1) HM_CHECK_HIP(hipEventRecord(ev1, st));
 
     const bool robust = it >= cfg->robust_iter;                             // optimizer.py:145,183
     RowSegment segs[3];

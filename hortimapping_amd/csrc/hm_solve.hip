@@ -88,15 +88,83 @@ __device__ __forceinline__ double wave_sum(double v) {
 
 }  // namespace
 
+constexpr int NBK = (MAX_E + 31) / 32;   // 32-wide blocks of the unknown vector (9 for E <= 263)
+
+// Blocked triangular solves on the packed factor in LDS.  `rv` holds the right-hand side on entry and the solution
+// on exit.  Diagonal 32x32 blocks are solved by one wavefront with lane-parallel column updates (no reductions on
+// the serial chain); the off-diagonal updates are spread over the whole workgroup.
+__device__ void solve_packed(const float* Lp, float* rv, int E, int tid) {
+  const int lane = tid & 63, wv = tid >> 6;
+  const int nblk = (E + 31) / 32;
+  // forward: L y = r
+  for (int bb = 0; bb < nblk; ++bb) {
+    const int base = bb * 32;
+    if (wv == 0) {
+      const int i = base + (lane & 31);
+      const bool ok = i < E;
+      float ri = ok ? rv[i] : 0.f;
+      float lrow[32];
+#pragma unroll
+      for (int jj = 0; jj < 32; ++jj) lrow[jj] = (ok && base + jj <= i) ? Lp[tri(i, base + jj)] : 1.f;
+#pragma unroll
+      for (int jj = 0; jj < 32; ++jj) {
+        const float num = __shfl(ri, jj);
+        const float ljj = __shfl(lrow[jj], jj);
+        const float yj = num / ljj;
+        if ((lane & 31) == jj) ri = yj;
+        else if ((lane & 31) > jj) ri -= lrow[jj] * yj;
+      }
+      if (lane < 32 && ok) rv[i] = ri;
+    }
+    __syncthreads();
+    for (int i = base + 32 + tid; i < E; i += NT) {
+      float s = 0.f;
+      const float* lr = Lp + tri(i, base);
+#pragma unroll 8
+      for (int kk = 0; kk < 32; ++kk) s = fmaf(lr[kk], rv[base + kk], s);
+      rv[i] -= s;
+    }
+    __syncthreads();
+  }
+  // backward: L^T x = y
+  for (int bb = nblk - 1; bb >= 0; --bb) {
+    const int base = bb * 32;
+    if (wv == 0) {
+      const int j = base + (lane & 31);
+      const bool ok = j < E;
+      float sj = ok ? rv[j] : 0.f;
+      for (int ii = 31; ii >= 0; --ii) {
+        const int i = base + ii;
+        if (i >= E) continue;
+        const float lii = Lp[tri(i, i)];
+        const float xi = __shfl(sj, ii) / lii;
+        const float lij = (ok && j < i) ? Lp[tri(i, j)] : 0.f;
+        if ((lane & 31) == ii) sj = xi;
+        else if ((lane & 31) < ii) sj -= lij * xi;
+      }
+      if (lane < 32 && ok) rv[j] = sj;
+    }
+    __syncthreads();
+    const int hi = (base + 32 < E) ? base + 32 : E;
+    for (int j = tid; j < base; j += NT) {
+      float s = 0.f;
+      for (int i = base; i < hi; ++i) s = fmaf(Lp[tri(i, j)], rv[i], s);
+      rv[j] -= s;
+    }
+    __syncthreads();
+  }
+}
+
 __global__ __launch_bounds__(NT) void k_solve_update(const SolveArgs a) {
-  __shared__ float Lp[MAX_E * (MAX_E + 1) / 2];   // packed lower triangle (<= 139 KiB)
-  __shared__ float cj[MAX_E + 1];
-  __shared__ float bvec[MAX_E + 1];
-  __shared__ float xvec[MAX_E + 1];
-  __shared__ float dvec[MAX_E + 1];
-  __shared__ float diagA[MAX_E + 1];
-  __shared__ double rvec[MAX_E + 1];
+  __shared__ float Lp[MAX_E * (MAX_E + 1) / 2];   // packed lower-triangular Cholesky factor (<= 139 KiB)
+  __shared__ float cj[NBK * 32];
+  __shared__ float bvec[NBK * 32];
+  __shared__ float xvec[NBK * 32];
+  __shared__ float rv[NBK * 32];
+  __shared__ float diagA[NBK * 32];
   __shared__ float red[NT / 64];
+  __shared__ float red2[NT / 64];
+  __shared__ float sh_piv;
   __shared__ int flag;
 
   const int b = blockIdx.x;
@@ -109,6 +177,7 @@ __global__ __launch_bounds__(NT) void k_solve_update(const SolveArgs a) {
   const int L = a.L, P = a.P, E = L + P, ld = a.ldJ;
   const float* H = a.Hext + (size_t)b * ld * ld;
   float* z = a.latent + (size_t)b * a.ld_latent;
+  const int lane = tid & 63, wv = tid >> 6;
 
   // ---- assemble (optimizer.py:200-231) ----
   for (int i = tid; i < E; i += NT) {
@@ -118,6 +187,7 @@ __global__ __launch_bounds__(NT) void k_solve_update(const SolveArgs a) {
     diagA[i] = d;
     bvec[i] = -H[(size_t)(L + 7) * ld + i] - (i < L ? a.w_code * z[i] : 0.f);   // :153,190,202-203
   }
+  if (tid == 0) flag = 0;
   __syncthreads();
   if (a.lm_on) {                                                // :220-225
     if (a.lm_eye) {
@@ -125,7 +195,7 @@ __global__ __launch_bounds__(NT) void k_solve_update(const SolveArgs a) {
       for (int i = tid; i < E; i += NT) mx = fmaxf(mx, diagA[i]);
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-      if ((tid & 63) == 0) red[tid >> 6] = mx;
+      if (lane == 0) red[wv] = mx;
       __syncthreads();
       mx = red[0];
       for (int i = 1; i < NT / 64; ++i) mx = fmaxf(mx, red[i]);
@@ -136,85 +206,95 @@ __global__ __launch_bounds__(NT) void k_solve_update(const SolveArgs a) {
     }
   }
   __syncthreads();
-  for (int i = tid >> 5; i < E; i += NT / 32)
-    for (int k = tid & 31; k <= i; k += 32) Lp[tri(i, k)] = (i == k) ? diagA[i] : H[(size_t)i * ld + k];
+
+  // ---- register-resident right-looking Cholesky: thread (ti, tk) owns A[32 bi + ti][32 bk + tk], bk <= bi ----
+  const int tk = tid & 31, ti = tid >> 5;
+  float A[NBK][NBK];
+#pragma unroll
+  for (int bi = 0; bi < NBK; ++bi)
+#pragma unroll
+    for (int bk = 0; bk <= bi; ++bk) {
+      const int i = bi * 32 + ti, k = bk * 32 + tk;
+      float v = 0.f;
+      if (i < E && k <= i) v = (i == k) ? diagA[i] : H[(size_t)i * ld + k];
+      A[bi][bk] = v;
+    }
   if (a.dbg_A != nullptr) {
-    float* A = a.dbg_A + (size_t)b * ld * ld;
-    for (int i = tid >> 5; i < E; i += NT / 32)
-      for (int k = tid & 31; k <= i; k += 32) A[(size_t)i * ld + k] = (i == k) ? diagA[i] : H[(size_t)i * ld + k];
+    float* Ad = a.dbg_A + (size_t)b * ld * ld;
+#pragma unroll
+    for (int bi = 0; bi < NBK; ++bi)
+#pragma unroll
+      for (int bk = 0; bk <= bi; ++bk) {
+        const int i = bi * 32 + ti, k = bk * 32 + tk;
+        if (i < E && k <= i) Ad[(size_t)i * ld + k] = A[bi][bk];
+      }
   }
   if (a.dbg_b != nullptr)
     for (int i = tid; i < E; i += NT) a.dbg_b[(size_t)b * ld + i] = bvec[i];
-  if (tid == 0) flag = 0;
-  __syncthreads();
 
-  // ---- Cholesky, right-looking, cyclic 32x32 thread grid over the packed triangle ----
-  const int tk = tid & 31, ti = tid >> 5;
-  for (int j = 0; j < E; ++j) {
-    const float piv = Lp[tri(j, j)];
-    if (!(piv > 0.f)) { if (tid == 0) flag = 1; }
-    const float d = sqrtf(piv);
-    const float inv = 1.f / d;
-    for (int i = j + 1 + tid; i < E; i += NT) {
-      const float l = Lp[tri(i, j)] * inv;
-      Lp[tri(i, j)] = l;
-      cj[i] = l;
+#pragma unroll
+  for (int bj = 0; bj < NBK; ++bj) {
+    for (int tj = 0; tj < 32; ++tj) {
+      const int j = bj * 32 + tj;
+      if (j >= E) break;
+      if (ti == tj && tk == tj) sh_piv = A[bj][bj];
+      __syncthreads();
+      const float piv = sh_piv;
+      if (!(piv > 0.f)) flag = 1;
+      const float d = sqrtf(piv);
+      const float inv = 1.f / d;
+      if (tk == tj) {
+#pragma unroll
+        for (int bi = bj; bi < NBK; ++bi) {
+          const int i = bi * 32 + ti;
+          if (i > j && i < E) {
+            const float l = A[bi][bj] * inv;
+            A[bi][bj] = l;
+            cj[i] = l;
+            Lp[tri(i, j)] = l;
+          } else if (i == j) {
+            Lp[tri(j, j)] = d;
+          }
+        }
+      }
+      __syncthreads();
+      float ci[NBK], ck[NBK];
+#pragma unroll
+      for (int bb = bj; bb < NBK; ++bb) { ci[bb] = cj[bb * 32 + ti]; ck[bb] = cj[bb * 32 + tk]; }
+#pragma unroll
+      for (int bi = bj; bi < NBK; ++bi)
+#pragma unroll
+        for (int bk = bj; bk <= bi; ++bk) {
+          const int i = bi * 32 + ti, k = bk * 32 + tk;
+          if (k > j && k <= i && i < E) A[bi][bk] = fmaf(-ci[bi], ck[bk], A[bi][bk]);
+        }
     }
-    __syncthreads();
-    if (tid == 0) Lp[tri(j, j)] = d;
-    const int j1 = j + 1;
-    int i0 = j1 + ((ti - (j1 & 31)) & 31);
-    int k0 = j1 + ((tk - (j1 & 31)) & 31);
-    for (int i = i0; i < E; i += 32) {
-      const float li = cj[i];
-      for (int k = k0; k <= i; k += 32) Lp[tri(i, k)] -= li * cj[k];
-    }
-    __syncthreads();
   }
+  __syncthreads();
   if (flag) {
     if (tid == 0) { a.active[b] = 0; a.status[b] |= HM_STATUS_SOLVE_FAILED; }
     return;
   }
 
-  // ---- solve L L^T x = b, then one refinement step with an fp64 residual ----
-  const int lane = tid & 63, wv = tid >> 6;
-  for (int pass = 0; pass < 2; ++pass) {
-    if (pass == 1) {
-      // r = b - A x  (A = damped normal matrix, fp32 entries, fp64 accumulation), one wave per row
-      for (int i = wv; i < E; i += NT / 64) {
-        double s = 0.0;
-        for (int k = lane; k < E; k += 64) {
-          const float aik = (k == i) ? diagA[i] : (k < i ? H[(size_t)i * ld + k] : H[(size_t)k * ld + i]);
-          s += (double)aik * (double)xvec[k];
-        }
-        s = wave_sum(s);
-        if (lane == 0) rvec[i] = (double)bvec[i] - s;
-      }
-    } else {
-      for (int i = tid; i < E; i += NT) rvec[i] = (double)bvec[i];
+  // ---- solve L L^T x = b (fp32), then one refinement step with an fp64 residual from the fp32 system ----
+  for (int i = tid; i < NBK * 32; i += NT) { rv[i] = i < E ? bvec[i] : 0.f; xvec[i] = 0.f; }
+  __syncthreads();
+  solve_packed(Lp, rv, E, tid);
+  for (int i = tid; i < E; i += NT) xvec[i] = rv[i];
+  __syncthreads();
+  for (int i = wv; i < E; i += NT / 64) {
+    double s = 0.0;
+    for (int k = lane; k < E; k += 64) {
+      const float aik = (k == i) ? diagA[i] : (k < i ? H[(size_t)i * ld + k] : H[(size_t)k * ld + i]);
+      s += (double)aik * (double)xvec[k];
     }
-    __syncthreads();
-    if (wv == 0) {
-      // forward substitution, one wave, fp64 dot products
-      for (int j = 0; j < E; ++j) {
-        double s = 0.0;
-        for (int k = lane; k < j; k += 64) s += (double)Lp[tri(j, k)] * (double)dvec[k];
-        s = wave_sum(s);
-        if (lane == 0) dvec[j] = (float)((rvec[j] - s) / (double)Lp[tri(j, j)]);
-        __builtin_amdgcn_wave_barrier();
-      }
-      for (int j = E - 1; j >= 0; --j) {
-        double s = 0.0;
-        for (int i = j + 1 + lane; i < E; i += 64) s += (double)Lp[tri(i, j)] * (double)cj[i];
-        s = wave_sum(s);
-        if (lane == 0) cj[j] = (float)(((double)dvec[j] - s) / (double)Lp[tri(j, j)]);
-        __builtin_amdgcn_wave_barrier();
-      }
-    }
-    __syncthreads();
-    for (int i = tid; i < E; i += NT) xvec[i] = (pass == 0) ? cj[i] : xvec[i] + cj[i];
-    __syncthreads();
+    s = wave_sum(s);
+    if (lane == 0) rv[i] = (float)((double)bvec[i] - s);
   }
+  __syncthreads();
+  solve_packed(Lp, rv, E, tid);
+  for (int i = tid; i < E; i += NT) xvec[i] += rv[i];
+  __syncthreads();
   if (a.dbg_delta != nullptr)
     for (int i = tid; i < E; i += NT) a.dbg_delta[(size_t)b * ld + i] = xvec[i];
 
@@ -231,7 +311,6 @@ __global__ __launch_bounds__(NT) void k_solve_update(const SolveArgs a) {
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) { mg = fmaxf(mg, __shfl_xor(mg, o)); mc = fmaxf(mc, __shfl_xor(mc, o)); }
-  __shared__ float red2[NT / 64];
   if (lane == 0) { red[wv] = mg; red2[wv] = mc; }
   if (bad) flag = 1;
   __syncthreads();

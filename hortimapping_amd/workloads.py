@@ -1,0 +1,72 @@
+"""Synthetic workloads of BASELINE.json / SURVEY.md 8d (data generators; nothing here is timed)."""
+from __future__ import annotations
+
+import copy
+
+import numpy as np
+import torch
+
+from . import ops, synthetic as S
+from .decoder import DecoderWeights
+from .optimizer import Instance
+
+# the `opt:` block of configs/wild_pepper.yaml (values), benchmark overrides applied by c2_opt_cfg()
+WILD_PEPPER_OPT = {
+    "scale_on": True,
+    "lm": {"lm_on": True, "lm_eye": False, "lm_lambda_0": 0.1, "s_damp": 1e-3},
+    "pose_init": {"rot_on": True, "scale_on": True},
+    "recon": {"n_pts": 2000, "cluster_dist_m": 0.01, "robust_th_m": 0.01},
+    "render": {"n_fg_pix": 200, "n_bg_pix": 200, "n_bg_pad": 20, "n_frame": 10, "n_sample_on_ray": 30,
+               "log_sdf_occ": True, "occ_cutoff_m": 0.01, "occlusion_on": True, "robust_th_m": 0.05},
+    "weight": {"w_recon": 1.0, "w_depth": 5e-2, "w_mask": 5e-4, "w_codereg": 5e-4},
+    "converge": {"max_iter": 50, "epsilon_g": 1e-4, "epsilon_c": 1e-2, "epsilon_t": 1e-3, "epsilon_r": 1.0,
+                 "epsilon_s": 1e-3},
+    "robust_iter": 5,
+    "outlier": {"scale_max": 1.25, "scale_min": 0.5, "rot_max_deg": 60},
+}
+
+
+def c2_opt_cfg(max_iter=200, n_sample_on_ray=16, n_frame=1):
+    """C2: wild_pepper weights, 200 forced iterations (all epsilon = 0), robust_iter 5, Sim(3)."""
+    o = copy.deepcopy(WILD_PEPPER_OPT)
+    o["converge"].update(max_iter=max_iter, epsilon_g=0.0, epsilon_c=0.0, epsilon_t=0.0, epsilon_r=0.0, epsilon_s=0.0)
+    o["render"].update(n_sample_on_ray=n_sample_on_ray, n_frame=n_frame)
+    return o
+
+
+def gpu_sdf_factory(dec: DecoderWeights, device="cuda"):
+    """sdf(x) callables backed by hm_decode_batch -- used only to *generate* synthetic observations quickly."""
+    def factory(z_true):
+        zt = torch.from_numpy(np.asarray(z_true, dtype=np.float32)).to(device)[None].contiguous()
+
+        def f(p):
+            p = np.asarray(p, dtype=np.float32).reshape(-1, 3)
+            n = p.shape[0]
+            npad = (n + 63) // 64 * 64
+            pts4 = torch.zeros(1, npad, 4, device=device)
+            pts4[0, :n, :3] = torch.from_numpy(p).to(device)
+            y, _ = ops.decode_batch(dec, zt, pts4, torch.tensor([n], dtype=torch.int32, device=device), mode=0)
+            return y[0, :n].double().cpu().numpy()
+        return f
+    return factory
+
+
+def make_c2_instances(params, dec, ids, kind="joint", device="cuda"):
+    """C2-joint: 1024 surface points + 1 frame x (32 fg + 32 bg) rays; C2-sdf: 2048 surface points, no rays."""
+    Ws, bs = S.fold_weight_norm(params)
+    L = int(params["latent_dim"])
+    fac = gpu_sdf_factory(dec, device) if (dec is not None and torch.cuda.is_available()) else None
+    out = []
+    for i in ids:
+        if kind == "joint":
+            d = S.make_instance(Ws, bs, L, i, n_pts=1024, n_frames=1, n_fg=32, n_bg=32, sdf_fn_factory=fac)
+        else:
+            d = S.make_instance(Ws, bs, L, i, n_pts=2048, n_frames=1, n_fg=4, n_bg=4, sdf_fn_factory=fac)
+        out.append(d)
+    return out
+
+
+def to_instance(d, pose_known=False) -> Instance:
+    rd = {k: [torch.from_numpy(a) for a in v] for k, v in d["render"].items()}
+    return Instance(torch.from_numpy(d["latent0"].copy()), torch.from_numpy(d["T_ow0"].copy()),
+                    torch.from_numpy(d["points_w"]), rd, float(d["cube_radius"]), pose_known)

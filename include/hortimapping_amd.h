@@ -128,6 +128,12 @@ int hm_workspace_create(hm_decoder_t dec, const hm_limits* limits, hm_workspace_
 int hm_workspace_destroy(hm_workspace_t ws);
 size_t hm_workspace_bytes(hm_workspace_t ws);
 
+/* Measurement aid: when enabled, hm_optimize_batch brackets every SDF-term decoder launch (the dominant kernel,
+ * k_decoder<1,0>) with HIP events on the caller's stream.  hm_workspace_profile_read returns the summed duration
+ * [ms] and the number of launches since the last enable; call it only after synchronising the stream. */
+int hm_workspace_profile(hm_workspace_t ws, int enable);
+int hm_workspace_profile_read(hm_workspace_t ws, double* ms_total, long long* launches);
+
 /* Replaces Optimizer.shape_pose_joint_opt (mode 0; optimizer.py:28-302) and Optimizer.shape_opt_deepsdf (mode 1;
  * optimizer.py:306-429) for a whole batch.  Enqueues cfg->max_iter iterations on `stream` with no host sync;
  * instances that converge / become invalid are frozen bit-exactly by device-side flags. */
