@@ -99,7 +99,7 @@ int launch_transform_points(const float* d_points_w, int n_in_stride, const int*
                             const int* d_active, int B, int n_stride, float* d_pts4, hipStream_t stream);
 
 int launch_render_front(const RenderCfg& cfg, const RenderBuffers& rb, const float* d_T_ow, const int* d_active,
-                        int B, hipStream_t stream);          // frame setup + ray sampling
+                        int B, hipStream_t stream, const float* d_frame_override = nullptr);   // frame setup + ray sampling
 int launch_render_scan(const RenderCfg& cfg, const RenderBuffers& rb, const int* d_active, int B,
                        hipStream_t stream);                  // ray scan + offsets + scatter
 int launch_render_reduce(const RenderCfg& cfg, const RenderBuffers& rb, const int* d_active, int B, int L,

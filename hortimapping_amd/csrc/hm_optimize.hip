@@ -132,9 +132,9 @@ void bind_inputs(RenderBuffers& rb, const hm_batch* bt) {
 
 // render front end + Jacobian pass + per-ray reduce for the current state (optimizer.py:93-132)
 int render_pass(hm_workspace_s* ws, const RenderCfg& rc, const RenderBuffers& rb, const hm_batch* bt, int P,
-                const int* d_active, hipStream_t st) {
+                const int* d_active, hipStream_t st, const float* d_frame_override = nullptr) {
   const int B = bt->B;
-  int rc_ = launch_render_front(rc, rb, bt->d_T_ow, d_active, B, st);
+  int rc_ = launch_render_front(rc, rb, bt->d_T_ow, d_active, B, st, d_frame_override);
   if (rc_) return rc_;
   rc_ = launch_decoder(ws->dec, B, rb.ptsR, rb.nRq, d_active, ws->nR_stride, ws->c0, ws->c4, rb.sdfR, nullptr, 0, 0, 0, st);
   if (rc_) return rc_;
@@ -289,8 +289,9 @@ extern "C" int hm_optimize_batch(hm_workspace_s* ws, const hm_opt_cfg* cfg, cons
   return 0;
 }
 
-extern "C" int hm_render_residuals(hm_workspace_s* ws, const hm_opt_cfg* cfg, const hm_batch* bt, float* d_rows,
-                                   int* d_V, int* d_ray_row, int* d_counts, void* stream) {
+extern "C" int hm_render_residuals(hm_workspace_s* ws, const hm_opt_cfg* cfg, const hm_batch* bt,
+                                   const float* d_frame_override, float* d_rows, int* d_V, int* d_ray_row,
+                                   int* d_counts, void* stream) {
   if (ws == nullptr || cfg == nullptr) { hm_set_error("null argument"); return -1; }
   int rc = check_batch(ws, bt, 0);
   if (rc) return rc;
@@ -303,7 +304,7 @@ extern "C" int hm_render_residuals(hm_workspace_s* ws, const hm_opt_cfg* cfg, co
   bind_inputs(rb, bt);
   rc = launch_latent_bias(ws->dec, bt->d_latent, L, nullptr, B, ws->c0, ws->c4, st);
   if (rc) return rc;
-  rc = render_pass(ws, rcfg, rb, bt, P, nullptr, st);
+  rc = render_pass(ws, rcfg, rb, bt, P, nullptr, st, d_frame_override);
   if (rc) return rc;
   const size_t per_inst = (size_t)2 * ws->nray * ws->ldJ;
   if (d_rows) HM_CHECK_HIP(hipMemcpyAsync(d_rows, rb.JR, per_inst * B * sizeof(float), hipMemcpyDeviceToDevice, st));

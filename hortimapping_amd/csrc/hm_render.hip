@@ -56,7 +56,7 @@ __global__ void k_transform_points(const float* __restrict__ pw, int n_in_stride
 }
 
 __global__ void k_frame_setup(const RenderCfg cfg, const RenderBuffers rb, const float* __restrict__ T_ow,
-                              const int* __restrict__ active) {
+                              const int* __restrict__ active, const float* __restrict__ frame_override) {
   const int b = blockIdx.x;
   if (active != nullptr && active[b] == 0) return;
   const int f = threadIdx.x;
@@ -65,6 +65,11 @@ __global__ void k_frame_setup(const RenderCfg cfg, const RenderBuffers rb, const
   if (f >= cfg.F) return;
   rb.valid_count[b * cfg.F + f] = 0;
   if (f >= nf) return;
+  if (frame_override != nullptr) {   // functional hook: caller supplies T_oc | d_min | d_max | ball radius directly
+    float* fp = rb.frame + ((size_t)b * cfg.F + f) * 16;
+    for (int i = 0; i < 16; ++i) fp[i] = frame_override[((size_t)b * cfg.F + f) * 16 + i];
+    return;
+  }
   const float* T = T_ow + (size_t)b * 16;
   const float* C = rb.T_wc + ((size_t)b * cfg.F + f) * 16;
   float Toc[12];
@@ -309,8 +314,8 @@ int launch_transform_points(const float* d_points_w, int n_in_stride, const int*
 }
 
 int launch_render_front(const RenderCfg& cfg, const RenderBuffers& rb, const float* d_T_ow, const int* d_active,
-                        int B, hipStream_t stream) {
-  hipLaunchKernelGGL(k_frame_setup, dim3(B), dim3(64), 0, stream, cfg, rb, d_T_ow, d_active);
+                        int B, hipStream_t stream, const float* d_frame_override) {
+  hipLaunchKernelGGL(k_frame_setup, dim3(B), dim3(64), 0, stream, cfg, rb, d_T_ow, d_active, d_frame_override);
   HM_CHECK_HIP(hipGetLastError());
   dim3 grid((cfg.R * cfg.M + 255) / 256, cfg.F, B);
   hipLaunchKernelGGL(k_sample_rays, grid, dim3(256), 0, stream, cfg, rb, d_active);

@@ -64,7 +64,7 @@ def _declare_opt(lib):
     lib.hm_optimize_batch.argtypes = [_vp, ctypes.POINTER(HmOptCfg), ctypes.POINTER(HmBatch), ctypes.c_int,
                                       ctypes.POINTER(HmDebug), _vp]
     lib.hm_render_residuals.restype = ctypes.c_int
-    lib.hm_render_residuals.argtypes = [_vp, ctypes.POINTER(HmOptCfg), ctypes.POINTER(HmBatch), _vp, _vp, _vp, _vp, _vp]
+    lib.hm_render_residuals.argtypes = [_vp, ctypes.POINTER(HmOptCfg), ctypes.POINTER(HmBatch), _vp, _vp, _vp, _vp, _vp, _vp]
     lib._hm_opt_declared = True
 
 

@@ -1,0 +1,60 @@
+"""Functional mirrors of the reference's decoder helpers (`wild_completion/utils.py`), GPU-backed.
+
+Same names, argument meaning and return shapes as the reference; `decoder` is a `DecoderWeights` bundle (or the
+reference's nn.Module, which is converted once).  No CPU fallback: these call libhortihip.so."""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import ops
+from .decoder import DecoderWeights
+
+_CONVERTED = {}
+
+
+def as_weights(decoder) -> DecoderWeights:
+    if isinstance(decoder, DecoderWeights):
+        return decoder
+    key = id(decoder)
+    if key not in _CONVERTED:
+        _CONVERTED[key] = DecoderWeights.from_module(decoder)
+    return _CONVERTED[key]
+
+
+def _pack_points(x: torch.Tensor, device):
+    x = x.detach().to(device=device, dtype=torch.float32).reshape(-1, 3)
+    n = x.shape[0]
+    npad = max(64, (n + 63) // 64 * 64)
+    pts4 = torch.zeros(1, npad, 4, device=device, dtype=torch.float32)
+    pts4[0, :n, :3] = x
+    return pts4, n
+
+
+def decode_sdf(decoder, lat_vec, x, max_batch=64 ** 3):
+    """`wild_completion/utils.py:144-172`: sdf values (N,) of query points x (N,3) under latent `lat_vec` (L,)."""
+    dec = as_weights(decoder)
+    dev = torch.device("cuda")
+    pts4, n = _pack_points(x, dev)
+    lat = lat_vec.detach().to(dev, torch.float32).reshape(1, -1).contiguous()
+    y, _ = ops.decode_batch(dec, lat, pts4, torch.tensor([n], dtype=torch.int32, device=dev), mode=0)
+    return y[0, :n]
+
+
+def get_batch_sdf_jacobian(decoder, lat_vec, x):
+    """`wild_completion/utils.py:175-193`: (y (n,1,1), g (n,1,L+3)) with g = d sdf / d [latent ; xyz]."""
+    dec = as_weights(decoder)
+    dev = torch.device("cuda")
+    L = dec.latent_dim
+    pts4, n = _pack_points(x, dev)
+    lat = lat_vec.detach().to(dev, torch.float32).reshape(1, -1).contiguous()
+    y, J = ops.decode_batch(dec, lat, pts4, torch.tensor([n], dtype=torch.int32, device=dev), mode=1, pose_dim=0)
+    g = torch.cat([J[0, :n, :L], J[0, :n, L:L + 3]], dim=1)
+    return y[0, :n].reshape(n, 1, 1), g.reshape(n, 1, L + 3)
+
+
+def get_rays(sampled_pixels, invK):
+    """`wild_completion/utils.py:23-37`: camera-frame ray directions (z = 1) of pixels [u, v] (host-side data prep)."""
+    n = sampled_pixels.shape[0]
+    u_hom = np.concatenate([sampled_pixels, np.ones((n, 1))], axis=-1)
+    return (u_hom[:, None, :] * invK).sum(-1).astype(np.float32)

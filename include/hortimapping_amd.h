@@ -143,9 +143,15 @@ int hm_optimize_batch(hm_workspace_t ws, const hm_opt_cfg* cfg, const hm_batch* 
 /* Replaces one call of compute_render_loss per frame (wild_completion/loss.py:8-217) for a batch: runs the render
  * front end + Jacobian pass for the current (latent, T_ow) and leaves, per instance, V[b] depth rows followed (at row
  * offset max_frames*max_rays) by V[b] mask rows of L+8 floats [d res/d z | d res/d pose | res] in d_rows
- * ([B][2*max_frames*max_rays][L+8]); d_V[b] = emitted rays, d_ray_row[b][ray] = row of that ray or -1. */
-int hm_render_residuals(hm_workspace_t ws, const hm_opt_cfg* cfg, const hm_batch* batch, float* d_rows,
-                        int* d_V, int* d_ray_row, int* d_counts, void* stream);
+ * ([B][2*max_frames*max_rays][L+8]); d_V[b] = emitted rays, d_ray_row[b][ray] = row of that ray or -1 (rays are
+ * emitted in ascending ray index, fg first: the order torch.unique gives the reference, loss.py:160-166).
+ * d_frame_override (optional, [B][max_frames][16]): per frame  T_oc rows 0..2 (12 floats) | d_min | d_max | ball
+ * radius | 0, i.e. exactly the arguments `t_obj_cam`, `sampled_ray_depth = linspace(d_min, d_max, M)` and
+ * `object_bbx_radius` of compute_render_loss; when NULL they are derived from T_ow and T_wc as the optimiser does
+ * (wild_completion/optimizer.py:103-111). */
+int hm_render_residuals(hm_workspace_t ws, const hm_opt_cfg* cfg, const hm_batch* batch,
+                        const float* d_frame_override, float* d_rows, int* d_V, int* d_ray_row, int* d_counts,
+                        void* stream);
 
 #ifdef __cplusplus
 }
