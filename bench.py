@@ -159,6 +159,10 @@ def main():
         flops_per_launch = n_s * FLOP_FWD_BWD                     # SDF-term K1 launch: all B instances' surface points
         avg_ms = ms_tot.value / max(1, n_launch.value)
         achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12
+        traffic = None        # HBM/fabric bytes per launch from the committed PMC passes (same workload only)
+        tj = os.path.join(ROOT, "profiles", "r01_traffic.json")
+        if kind == "joint" and B == 64 and L == 256 and os.path.exists(tj):
+            traffic = json.load(open(tj))["bytes_per_launch"]
         out = {
             "metric": "fruit-instances/sec full optimisation (200 iters, 2048 pts)",
             "value": round(value, 3), "unit": "instances/s", "n_gpus": world, "steps": args.steps,
@@ -176,7 +180,7 @@ def main():
             "roofline": {
                 "bound": "mfma", "kernel": "k_decoder<1,0> (SDF-term decoder forward + input-gradient backward)",
                 "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
                 "launches": int(n_launch.value), "avg_launch_ms": round(avg_ms, 4),
                 "algorithmic_flop_per_launch": flops_per_launch,
             },
