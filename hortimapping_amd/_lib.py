@@ -28,6 +28,10 @@ def _declare(lib):
     lib.hm_decoder_destroy.argtypes = [c_void_p]
     lib.hm_decoder_latent_dim.restype = c_int
     lib.hm_decoder_latent_dim.argtypes = [c_void_p]
+    lib.hm_decoder_set_precision.restype = c_int
+    lib.hm_decoder_set_precision.argtypes = [c_void_p, c_int]
+    lib.hm_decoder_get_precision.restype = c_int
+    lib.hm_decoder_get_precision.argtypes = [c_void_p]
     lib.hm_decode_batch.restype = c_int
     lib.hm_decode_batch.argtypes = [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p,
                                     c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]

@@ -35,9 +35,17 @@ struct StageDesc {
   int inst_bias;       // 0: bias ptr, 1: c0[b], 2: c4[b]
 };
 
+// f16x3 variant of a stage: A operands split into fp16 hi/lo at a per-stage power-of-two scale
+struct StageDescH {
+  const void* wp;      // packed [(mb - mb_lo)][k16 step][hi|lo][64 lanes][8 halves]
+  int n_k16;           // K steps of 16
+  float unscale;       // 2^-shift: accumulators hold 2^shift * (W X)
+};
+
 struct DecoderDev {
   int L, m, m_pad, mb_zx;        // m = 509 - L, m_pad = 512 - L, mb_zx = 16 - L/32
   StageDesc st[NSTAGE];
+  StageDescH sth[NSTAGE];
   const float* w8;               // [512]
   float b8;
   const float* w0x;              // [512][4]  xyz columns of lin0 (4th = 0)
@@ -52,6 +60,7 @@ struct DecoderDev {
 
 struct hm_decoder_s {
   hm::DecoderDev dev;
+  int precision;       // 0: exact fp32 MFMA, 1: fp16 hi/lo split (3 fp16 MFMA passes, ~2^-22 relative)
   void* d_blob;        // one allocation holding every packed array
   size_t blob_bytes;
   int L;

@@ -18,6 +18,7 @@
 // The latent part of lin0/lin4 is folded into a per-instance bias (c0, c4) for the forward pass; the
 // backward pass still produces the per-query d sdf / d z through the transposed latent columns.
 #include "hm_common.h"
+#include "hm_internal.h"
 
 using namespace hm;
 
@@ -365,6 +366,9 @@ int launch_decoder(const hm_decoder_s* dec, int B, const float* d_pts, const int
                    int n_stride, const float* d_c0, const float* d_c4, float* d_y, float* d_J, int ldJ,
                    int pose_dim, int mode, hipStream_t stream, int tag) {
   if (n_stride % TQ != 0) { hm_set_error("n_stride must be a multiple of %d", TQ); return -1; }
+  if (dec->precision == 1)
+    return launch_decoder_h(dec, B, d_pts, d_nq, d_active, n_stride, d_c0, d_c4, d_y, d_J, ldJ, pose_dim, mode,
+                            stream, tag);
   DecodeArgs a;
   a.dec = dec->dev;
   a.pts = d_pts; a.n_q = d_nq; a.active = d_active; a.c0 = d_c0; a.c4 = d_c4;

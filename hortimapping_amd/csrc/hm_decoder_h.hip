@@ -1,0 +1,387 @@
+// K1h: the fused decoder forward + input-gradient backward of hm_decoder.hip on the fp16 matrix cores
+// (v_mfma_f32_32x32x16_f16, 16x the rate of the fp32-input MFMA) with SPLIT OPERANDS so that the result keeps
+// ~2^-22 relative accuracy (fp32 class):
+//        W X  =  Wh Xh  +  Wh (X - Xh)  +  (W - Wh) Xh  +  O(2^-22)
+// All three products accumulate into ONE fp32 accumulator because the operands are pre-scaled by powers of two:
+//   weights by 2^s per stage, packed on the host as  hi = fp16(W 2^s),  lo = fp16(W 2^s - hi);
+//   the low part of the activations by 2^11:          Xh = fp16(X),     Xl' = fp16((X - Xh) 2^11);
+//   and the weight operand of the middle term by 2^-11 (an exact exponent shift, v_pk_mul_f16, in registers).
+// Every fp16 x fp16 product is exact in fp32 and the accumulator is fp32, so the only errors are the 2^-22 second
+// order term and fp32 summation rounding.  Activations live in LDS as two fp16 planes [k/8][q][8] (2 x 64 KiB).
+// Tiling, register-resident ReLU masks, latent folding and the VALU side paths are those of hm_decoder.hip
+// (reference: deepsdf/networks/deep_sdf_decoder.py:75-110, wild_completion/utils.py:112-193, loss.py:229-241).
+#include "hm_common.h"
+#include "hm_internal.h"
+
+using namespace hm;
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+struct DecodeArgsH {
+  DecoderDev dec;
+  const float* pts;
+  const int* n_q;
+  const int* active;
+  const float* c0;
+  const float* c4;
+  float* y;
+  float* J;
+  int n_stride;
+  int B;
+  int ldJ;
+  int pose_dim;
+};
+
+constexpr float LO_SCALE = 2048.f;          // 2^11
+constexpr float LO_UNSCALE = 1.f / 2048.f;
+
+__device__ __forceinline__ f32x16 zero16h() {
+  f32x16 z;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) z[i] = 0.f;
+  return z;
+}
+
+// split 4 consecutive-row values into the hi / scaled-lo fp16 planes (8 bytes each)
+__device__ __forceinline__ void split_store(f16x4* xh4, f16x4* xl4, int idx, const float (&v)[4]) {
+  f16x4 h, l;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const _Float16 hj = (_Float16)v[j];
+    h[j] = hj;
+    l[j] = (_Float16)((v[j] - (float)hj) * LO_SCALE);
+  }
+  xh4[idx] = h;
+  xl4[idx] = l;
+}
+
+template <bool U0, bool U1>
+__device__ __forceinline__ void gemm_loop_h(f32x16 (&acc)[2][2], const f16x8* __restrict__ wp0,
+                                            const f16x8* __restrict__ wp1, int n_k16, const f16x8* xh,
+                                            const f16x8* xl, int lane) {
+  const int xo = (lane >> 5) * TQ + (lane & 31);
+  const _Float16 cs = (_Float16)LO_UNSCALE;
+  f16x8 a0h = {}, a0l = {}, a1h = {}, a1l = {};
+  if (U0) { a0h = wp0[0]; a0l = wp0[64]; }
+  if (U1) { a1h = wp1[0]; a1l = wp1[64]; }
+  for (int ks = 0; ks < n_k16; ++ks) {
+    const int kn = (ks + 1 < n_k16) ? ks + 1 : ks;
+    f16x8 n0h = a0h, n0l = a0l, n1h = a1h, n1l = a1l;
+    if (U0) { n0h = wp0[kn * 128]; n0l = wp0[kn * 128 + 64]; }
+    if (U1) { n1h = wp1[kn * 128]; n1l = wp1[kn * 128 + 64]; }
+    const f16x8 b0h = xh[ks * 2 * TQ + xo], b1h = xh[ks * 2 * TQ + xo + 32];
+    const f16x8 b0l = xl[ks * 2 * TQ + xo], b1l = xl[ks * 2 * TQ + xo + 32];
+    if (U0) {
+      const f16x8 a0c = a0h * cs;
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, b0h, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, b1h, acc[0][1], 0, 0, 0);
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0c, b0l, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0c, b1l, acc[0][1], 0, 0, 0);
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0l, b0h, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0l, b1h, acc[0][1], 0, 0, 0);
+    }
+    if (U1) {
+      const f16x8 a1c = a1h * cs;
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, b0h, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, b1h, acc[1][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1c, b0l, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1c, b1l, acc[1][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1l, b0h, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1l, b1h, acc[1][1], 0, 0, 0);
+    }
+    a0h = n0h; a0l = n0l; a1h = n1h; a1l = n1l;
+  }
+}
+
+// X[k][q] as float for k = 8*grp + j (VALU side paths)
+__device__ __forceinline__ void load_group(const f16x8* xh, const f16x8* xl, int grp, int q, float (&x)[8]) {
+  const f16x8 h = xh[grp * TQ + q], l = xl[grp * TQ + q];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) x[j] = (float)h[j] + (float)l[j] * LO_UNSCALE;
+}
+
+#define HM_MASK_CASES(OP) \
+  case 0: OP(mk0); break; case 1: OP(mk1); break; case 2: OP(mk2); break; case 3: OP(mk3); break; \
+  case 4: OP(mk4); break; case 5: OP(mk5); break; case 6: OP(mk6); break; default: OP(mk7); break;
+
+template <int MODE, int TAG>
+__global__ __launch_bounds__(512, 2) void k_decoder_h(const DecodeArgsH a) {
+  __shared__ f16x8 xh[64 * TQ];    // 64 KiB: hi plane  X[k/8][q][8]
+  __shared__ f16x8 xl[64 * TQ];    // 64 KiB: lo plane (scaled by 2^11)
+  __shared__ float sc[2048 + 128];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int b = blockIdx.x % a.B;                 // tile-major block order (see hm_decoder.hip)
+  const int q0 = (blockIdx.x / a.B) * TQ;
+  if (a.active != nullptr && a.active[b] == 0) return;
+  const int nq = a.n_q[b];
+  if (q0 >= nq) return;
+  const int cnt = (nq - q0 < TQ) ? nq - q0 : TQ;
+
+  const int L = a.dec.L, m = a.dec.m, mb_zx = a.dec.mb_zx;
+  const size_t qbase = (size_t)b * a.n_stride + q0;
+  const int qa = lane & 31;
+  const int hi = lane >> 5;
+  const f32x4* pts4 = reinterpret_cast<const f32x4*>(a.pts);
+  const f32x4 pA = pts4[qbase + qa];
+  const f32x4 pB = pts4[qbase + qa + 32];
+  f16x4* xh4 = reinterpret_cast<f16x4*>(xh);
+  f16x4* xl4 = reinterpret_cast<f16x4*>(xl);
+
+  // stage 0 input: rows 0..2 = xyz, rows 3..15 = 0  (groups 0 and 1)
+  if (tid < TQ) {
+    const f32x4 p = pts4[qbase + tid];
+    const float v0[4] = {p[0], p[1], p[2], 0.f};
+    const float vz[4] = {0.f, 0.f, 0.f, 0.f};
+    split_store(xh4, xl4, (0 * TQ + tid) * 2 + 0, v0);
+    split_store(xh4, xl4, (0 * TQ + tid) * 2 + 1, vz);
+    split_store(xh4, xl4, (1 * TQ + tid) * 2 + 0, vz);
+    split_store(xh4, xl4, (1 * TQ + tid) * 2 + 1, vz);
+  }
+
+  uint2 mk0 = {0, 0}, mk1 = {0, 0}, mk2 = {0, 0}, mk3 = {0, 0}, mk4 = {0, 0}, mk5 = {0, 0}, mk6 = {0, 0},
+        mk7 = {0, 0};
+  f32x16 acc[2][2];
+  f32x16 accz[2] = {zero16h(), zero16h()};
+  float gx0 = 0.f, gx1 = 0.f, gx2 = 0.f;
+  float y_keep = 0.f;
+  const float* cbias0 = a.c0 + (size_t)b * HID;
+  const float* cbias4 = a.c4 + (size_t)b * HID;
+
+  constexpr int n_stage = MODE == 0 ? 8 : NSTAGE;
+  for (int s = 0; s < n_stage; ++s) {
+    const StageDesc& sd = a.dec.st[s];
+    const StageDescH& sh = a.dec.sth[s];
+    const int epi = sd.epi;
+    const int mb0 = w, mb1 = w + 8;
+    const bool u0 = (mb0 >= sd.mb_lo) && (mb0 < sd.mb_hi);
+    const bool u1 = (mb1 >= sd.mb_lo) && (mb1 < sd.mb_hi);
+    const float us = sh.unscale;
+    __syncthreads();
+
+    if (MODE == 1 && (epi == EPI_BWD4 || epi == EPI_BWD0)) {
+      const f32x4* wx = reinterpret_cast<const f32x4*>(epi == EPI_BWD4 ? a.dec.w4x : a.dec.w0x);
+#pragma unroll 2
+      for (int g = 0; g < 8; ++g) {
+        float x[8];
+        load_group(xh, xl, 8 * w + g, lane, x);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const f32x4 wv = wx[64 * w + 8 * g + j];
+          gx0 = fmaf(x[j], wv[0], gx0);
+          gx1 = fmaf(x[j], wv[1], gx1);
+          gx2 = fmaf(x[j], wv[2], gx2);
+        }
+      }
+    }
+
+    acc[0][0] = zero16h(); acc[0][1] = zero16h();
+    if (MODE == 1 && epi == EPI_BWD0) {
+      // the kept latent rows are in true units; this stage accumulates at 2^shift
+      const float rs = 1.f / us;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { acc[1][0][i] = accz[0][i] * rs; acc[1][1][i] = accz[1][i] * rs; }
+    } else { acc[1][0] = zero16h(); acc[1][1] = zero16h(); }
+
+    {
+      const f16x8* wp = reinterpret_cast<const f16x8*>(sh.wp);
+      const f16x8* wp0 = wp + (size_t)(mb0 - sd.mb_lo) * sh.n_k16 * 128 + lane;
+      const f16x8* wp1 = wp + (size_t)(mb1 - sd.mb_lo) * sh.n_k16 * 128 + lane;
+      if (u0 && u1) gemm_loop_h<true, true>(acc, wp0, wp1, sh.n_k16, xh, xl, lane);
+      else if (u0) gemm_loop_h<true, false>(acc, wp0, wp1, sh.n_k16, xh, xl, lane);
+      else if (u1) gemm_loop_h<false, true>(acc, wp0, wp1, sh.n_k16, xh, xl, lane);
+    }
+    __syncthreads();
+
+    if (MODE == 0 || epi <= EPI_FWD7) {
+      const float* bias = sd.inst_bias == 1 ? cbias0 : (sd.inst_bias == 2 ? cbias4 : sd.bias);
+      uint2 mk = {0, 0};
+#pragma unroll
+      for (int sl = 0; sl < 2; ++sl) {
+        const bool use = sl == 0 ? u0 : u1;
+        if (!use) continue;
+        const int mb = sl == 0 ? mb0 : mb1;
+        uint32_t bits = 0;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int f4 = mb * 32 + 8 * g + 4 * hi;
+          const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + f4);
+#pragma unroll
+          for (int nb = 0; nb < 2; ++nb) {
+            float v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const float val = fmaf(acc[sl][nb][4 * g + j], us, bv[j]);
+              const bool pos = val > 0.f;
+              bits |= (pos ? 1u : 0u) << (nb * 16 + 4 * g + j);
+              v[j] = pos ? val : 0.f;
+            }
+            if (epi == EPI_FWD3) {
+              const f32x4 p = nb == 0 ? pA : pB;
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                const int r = f4 + j - m;
+                if (r >= 0 && r < 3) v[j] = (r == 0 ? p[0] : (r == 1 ? p[1] : p[2]));
+              }
+            }
+            split_store(xh4, xl4, ((f4 >> 3) * TQ + nb * 32 + qa) * 2 + hi, v);
+          }
+        }
+        if (sl == 0) mk.x = bits; else mk.y = bits;
+      }
+#define HM_SET(M) M = mk
+      if (MODE == 1) switch (sd.layer) { HM_MASK_CASES(HM_SET) }
+#undef HM_SET
+
+      if (epi == EPI_FWD7) {
+        __syncthreads();
+        float part = 0.f;
+#pragma unroll 2
+        for (int g = 0; g < 8; ++g) {
+          float x[8];
+          load_group(xh, xl, 8 * w + g, lane, x);
+          const f32x4 w0 = *reinterpret_cast<const f32x4*>(a.dec.w8 + 64 * w + 8 * g);
+          const f32x4 w1 = *reinterpret_cast<const f32x4*>(a.dec.w8 + 64 * w + 8 * g + 4);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { part = fmaf(x[j], w0[j], part); }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { part = fmaf(x[4 + j], w1[j], part); }
+        }
+        sc[w * 64 + lane] = part;
+        __syncthreads();
+        float a8 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NWAVE; ++i) a8 += sc[i * 64 + lane];
+        a8 += a.dec.b8;
+        const float yv = tanhf(a8);
+        y_keep = yv;
+        if (w == 0) {
+          if (lane < cnt) a.y[qbase + lane] = yv;
+          sc[2048 + lane] = 1.f - yv * yv;
+        }
+        if (MODE == 0) return;
+        __syncthreads();
+        const float dyA = sc[2048 + qa], dyB = sc[2048 + 32 + qa];
+#pragma unroll
+        for (int sl = 0; sl < 2; ++sl) {
+          const int mb = sl == 0 ? mb0 : mb1;
+          const uint32_t bits = sl == 0 ? mk.x : mk.y;
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int f4 = mb * 32 + 8 * g + 4 * hi;
+            const f32x4 wv = *reinterpret_cast<const f32x4*>(a.dec.w8 + f4);
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) {
+              const float dy = nb == 0 ? dyA : dyB;
+              float v[4];
+#pragma unroll
+              for (int j = 0; j < 4; ++j) v[j] = ((bits >> (nb * 16 + 4 * g + j)) & 1u) ? dy * wv[j] : 0.f;
+              split_store(xh4, xl4, ((f4 >> 3) * TQ + nb * 32 + qa) * 2 + hi, v);
+            }
+          }
+        }
+      }
+    } else if (MODE == 1 && (epi == EPI_BWD || epi == EPI_BWD4)) {
+      uint2 mk;
+#define HM_GET(M) mk = M
+      switch (sd.layer) { HM_MASK_CASES(HM_GET) }
+#undef HM_GET
+#pragma unroll
+      for (int sl = 0; sl < 2; ++sl) {
+        const bool use = sl == 0 ? u0 : u1;
+        if (!use) continue;
+        const int mb = sl == 0 ? mb0 : mb1;
+        if (epi == EPI_BWD4 && mb >= mb_zx) {
+          if (sl == 1) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { accz[0][i] = acc[1][0][i] * us; accz[1][i] = acc[1][1][i] * us; }
+          }
+          continue;
+        }
+        const uint32_t bits = sl == 0 ? mk.x : mk.y;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int f4 = mb * 32 + 8 * g + 4 * hi;
+#pragma unroll
+          for (int nb = 0; nb < 2; ++nb) {
+            float v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              v[j] = ((bits >> (nb * 16 + 4 * g + j)) & 1u) ? acc[sl][nb][4 * g + j] * us : 0.f;
+            split_store(xh4, xl4, ((f4 >> 3) * TQ + nb * 32 + qa) * 2 + hi, v);
+          }
+        }
+      }
+    } else if (MODE == 1) {  // EPI_BWD0
+      if (u1) {
+        const int jz = (mb1 - mb_zx) * 32;
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+          const int q = nb * 32 + qa;
+          if (q < cnt) {
+            float* row = a.J + (qbase + q) * (size_t)a.ldJ;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              f32x4 v;
+#pragma unroll
+              for (int j = 0; j < 4; ++j) v[j] = acc[1][nb][4 * g + j] * us;
+              *reinterpret_cast<f32x4*>(row + jz + 8 * g + 4 * hi) = v;
+            }
+          }
+        }
+      }
+    }
+  }
+
+  if (MODE == 0) return;
+  sc[(w * 4 + 0) * 64 + lane] = gx0;
+  sc[(w * 4 + 1) * 64 + lane] = gx1;
+  sc[(w * 4 + 2) * 64 + lane] = gx2;
+  __syncthreads();
+  if (w == 0 && lane < cnt) {
+    float g0 = 0.f, g1 = 0.f, g2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NWAVE; ++i) {
+      g0 += sc[(i * 4 + 0) * 64 + lane];
+      g1 += sc[(i * 4 + 1) * 64 + lane];
+      g2 += sc[(i * 4 + 2) * 64 + lane];
+    }
+    const f32x4 p = pts4[qbase + lane];
+    float* row = a.J + (qbase + lane) * (size_t)a.ldJ + L;
+    row[7] = y_keep;
+    row[0] = g0; row[1] = g1; row[2] = g2;
+    if (a.pose_dim != 0) {
+      row[3] = g2 * p[1] - g1 * p[2];
+      row[4] = g0 * p[2] - g2 * p[0];
+      row[5] = g1 * p[0] - g0 * p[1];
+      if (a.pose_dim == 7) row[6] = g0 * p[0] + g1 * p[1] + g2 * p[2];
+    }
+  }
+}
+
+}  // namespace
+
+namespace hm {
+
+int launch_decoder_h(const hm_decoder_s* dec, int B, const float* d_pts, const int* d_nq, const int* d_active,
+                     int n_stride, const float* d_c0, const float* d_c4, float* d_y, float* d_J, int ldJ,
+                     int pose_dim, int mode, hipStream_t stream, int tag) {
+  DecodeArgsH a;
+  a.dec = dec->dev;
+  a.pts = d_pts; a.n_q = d_nq; a.active = d_active; a.c0 = d_c0; a.c4 = d_c4;
+  a.y = d_y; a.J = d_J; a.n_stride = n_stride; a.B = B; a.ldJ = ldJ; a.pose_dim = pose_dim;
+  const int grid = B * (n_stride / TQ);
+  if (grid == 0) return 0;
+  if (mode == 0) hipLaunchKernelGGL((k_decoder_h<0, 0>), dim3(grid), dim3(512), 0, stream, a);
+  else if (tag == 0) hipLaunchKernelGGL((k_decoder_h<1, 0>), dim3(grid), dim3(512), 0, stream, a);
+  else hipLaunchKernelGGL((k_decoder_h<1, 1>), dim3(grid), dim3(512), 0, stream, a);
+  HM_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace hm

@@ -12,6 +12,9 @@
 #include <functional>
 #include <vector>
 
+#include <hip/hip_fp16.h>
+#include <math.h>
+
 #include "hm_common.h"
 
 using namespace hm;
@@ -53,6 +56,36 @@ size_t pack_stage(Blob& blob, int mb_lo, int mb_hi, int n_kg, const std::functio
   return off;
 }
 
+// fp16 hi/lo packing of a stage for the f16x3 kernel.  With shift s (2^s * max|A| < 32768):
+//   hi = fp16(A * 2^s),  lo = fp16(A * 2^s - hi);   the kernel forms  hi*Xh + (hi*2^-11)*(Xl*2^11) + lo*Xh.
+// Layout [mb][k16][hi|lo][lane][8]: lane l holds row l&31, k = 16*step + 8*(l>>5) + j.
+size_t pack_stage_h(std::vector<uint16_t>& blob, int mb_lo, int mb_hi, int n_k16,
+                    const std::function<float(int, int)>& A, float* unscale) {
+  const int n_mb = mb_hi - mb_lo;
+  float mx = 0.f;
+  for (int r = mb_lo * 32; r < mb_hi * 32; ++r)
+    for (int c = 0; c < n_k16 * 16; ++c) mx = fmaxf(mx, fabsf(A(r, c)));
+  int shift = 12;
+  while (shift > -12 && ldexpf(mx, shift) >= 32768.f) --shift;
+  *unscale = ldexpf(1.f, -shift);
+  size_t off = (blob.size() + 63) & ~size_t(63);
+  blob.resize(off + (size_t)n_mb * n_k16 * 2 * 64 * 8, 0);
+  for (int mbi = 0; mbi < n_mb; ++mbi)
+    for (int ks = 0; ks < n_k16; ++ks)
+      for (int lane = 0; lane < 64; ++lane)
+        for (int j = 0; j < 8; ++j) {
+          const int r = (mb_lo + mbi) * 32 + (lane & 31);
+          const int c = ks * 16 + (lane >> 5) * 8 + j;
+          const float v = ldexpf(A(r, c), shift);
+          const __half hi = __float2half_rn(v);
+          const __half lo = __float2half_rn(v - __half2float(hi));
+          const size_t base = off + ((((size_t)mbi * n_k16 + ks) * 2) * 64 + lane) * 8 + j;
+          blob[base] = *reinterpret_cast<const uint16_t*>(&hi);
+          blob[base + 64 * 8] = *reinterpret_cast<const uint16_t*>(&lo);
+        }
+  return off;
+}
+
 }  // namespace
 
 extern "C" int hm_decoder_create(int latent_dim, const float* const* W, const float* const* bias,
@@ -68,6 +101,9 @@ extern "C" int hm_decoder_create(int latent_dim, const float* const* W, const fl
   auto w = [&](int l, int r, int c, int ld) { return W[l][(size_t)r * ld + c]; };
 
   Blob blob;
+  std::vector<uint16_t> hblob;
+  size_t hoff[NSTAGE];
+  StageDescH sth[NSTAGE];
   struct Pending { size_t wp, bias; int has_bias; };
   Pending pend[NSTAGE];
   StageDesc st[NSTAGE];
@@ -77,6 +113,13 @@ extern "C" int hm_decoder_create(int latent_dim, const float* const* W, const fl
     st[s].n_kg = n_kg; st[s].mb_lo = lo; st[s].mb_hi = hi; st[s].epi = epi; st[s].layer = layer;
     st[s].inst_bias = inst_bias;
     pend[s].wp = pack_stage(blob, lo, hi, n_kg, A);
+    {   // same stage for the f16x3 kernel: K padded to a multiple of 16 with zero columns
+      const int kmax = n_kg * 8;
+      const int n_k16 = (kmax + 15) / 16;
+      auto Ap = [&](int r, int c) { return c < kmax ? A(r, c) : 0.f; };
+      sth[s].n_k16 = n_k16;
+      hoff[s] = pack_stage_h(hblob, lo, hi, n_k16, Ap, &sth[s].unscale);
+    }
     pend[s].has_bias = 0;
     if (bfun) {
       pend[s].bias = blob.alloc(HID);
@@ -133,10 +176,14 @@ extern "C" int hm_decoder_create(int latent_dim, const float* const* W, const fl
 
   hm_decoder_s* d = new hm_decoder_s();
   d->L = L;
-  d->blob_bytes = blob.host.size() * sizeof(float);
+  d->precision = 0;
+  const size_t fbytes = (blob.host.size() * sizeof(float) + 255) & ~size_t(255);
+  d->blob_bytes = fbytes + hblob.size() * sizeof(uint16_t);
   hipError_t e = hipMalloc(&d->d_blob, d->blob_bytes);
   if (e != hipSuccess) { hm_set_error("hipMalloc(%zu) failed: %s", d->blob_bytes, hipGetErrorString(e)); delete d; return -2; }
-  e = hipMemcpy(d->d_blob, blob.host.data(), d->blob_bytes, hipMemcpyHostToDevice);
+  e = hipMemcpy(d->d_blob, blob.host.data(), blob.host.size() * sizeof(float), hipMemcpyHostToDevice);
+  if (e == hipSuccess)
+    e = hipMemcpy(static_cast<char*>(d->d_blob) + fbytes, hblob.data(), hblob.size() * sizeof(uint16_t), hipMemcpyHostToDevice);
   if (e != hipSuccess) { hm_set_error("hipMemcpy failed: %s", hipGetErrorString(e)); (void)hipFree(d->d_blob); delete d; return -2; }
   const float* base = static_cast<const float*>(d->d_blob);
   DecoderDev& dv = d->dev;
@@ -145,6 +192,8 @@ extern "C" int hm_decoder_create(int latent_dim, const float* const* W, const fl
     dv.st[s] = st[s];
     dv.st[s].wp = base + pend[s].wp;
     dv.st[s].bias = pend[s].has_bias ? base + pend[s].bias : nullptr;
+    dv.sth[s] = sth[s];
+    dv.sth[s].wp = static_cast<const char*>(d->d_blob) + fbytes + hoff[s] * sizeof(uint16_t);
   }
   dv.w8 = base + o_w8; dv.b8 = bias[8][0];
   dv.w0x = base + o_w0x; dv.w4x = base + o_w4x; dv.w0z = base + o_w0z; dv.w4z = base + o_w4z;
@@ -161,3 +210,12 @@ extern "C" int hm_decoder_destroy(hm_decoder_s* d) {
 }
 
 extern "C" int hm_decoder_latent_dim(const hm_decoder_s* d) { return d ? d->L : -1; }
+
+extern "C" int hm_decoder_set_precision(hm_decoder_s* d, int precision) {
+  if (d == nullptr) { hm_set_error("null decoder"); return -1; }
+  if (precision != 0 && precision != 1) { hm_set_error("precision must be 0 (f32) or 1 (f16x3)"); return -1; }
+  d->precision = precision;
+  return 0;
+}
+
+extern "C" int hm_decoder_get_precision(const hm_decoder_s* d) { return d ? d->precision : -1; }

@@ -62,6 +62,18 @@ class DecoderWeights:
         _lib.check(lib.hm_decoder_create(L, Wp, bp, ctypes.byref(h)), "hm_decoder_create")
         self.handle = h
 
+    PRECISIONS = {"f32": 0, "f16x3": 1}
+
+    def set_precision(self, name: str):
+        """'f32' (exact fp32 MFMA, default) or 'f16x3' (fp16 MFMA, hi/lo split operands, ~2^-22 relative)."""
+        _lib.check(_lib.lib().hm_decoder_set_precision(self.handle, self.PRECISIONS[name]), "hm_decoder_set_precision")
+        return self
+
+    @property
+    def precision(self) -> str:
+        v = _lib.lib().hm_decoder_get_precision(self.handle)
+        return {0: "f32", 1: "f16x3"}[v]
+
     @classmethod
     def from_params(cls, params):
         """`params`: dict of lin{l}.weight_v/weight_g/bias (+ lin8.weight) arrays plus 'latent_dim'."""

@@ -42,6 +42,13 @@ int hm_decoder_create(int latent_dim, const float* const* W, const float* const*
 int hm_decoder_destroy(hm_decoder_t dec);
 int hm_decoder_latent_dim(hm_decoder_t dec);
 
+/* Arithmetic of the decoder GEMMs (the reference computes in fp32, optimizer.py:19):
+ *   0  exact fp32 on the f32-input matrix cores (v_mfma_f32_32x32x2_f32; bitwise an fmaf chain)   [default]
+ *   1  "f16x3": fp16 matrix cores with hi/lo split operands, three MFMA passes into one fp32 accumulator,
+ *      ~2^-22 relative accuracy (fp32 class), 16/3 x the MFMA rate. */
+int hm_decoder_set_precision(hm_decoder_t dec, int precision);
+int hm_decoder_get_precision(hm_decoder_t dec);
+
 /* ---- functional parity hooks.
  * mode 0 replaces decode_sdf (wild_completion/utils.py:144-172): d_y[b][i] = sdf(latent_b, pts_b_i).
  * mode 1 replaces get_batch_sdf_jacobian (utils.py:175-193) and the chain rule of compute_sdf_loss

@@ -8,6 +8,8 @@ torch.manual_seed(0)
 for L in (32, 256, 128):
     p = S.make_synthetic_decoder(L, seed=5, aniso=(1.0, 0.75, 1.3), wn_perturb=0.05)
     dec = DecoderWeights.from_params(p)
+    import os
+    dec.set_precision(os.environ.get('HM_PREC','f32'))
     od = O.fold_decoder(p).to(torch.float64)
     B, n = 3, 200
     nq = [200, 70, 129]

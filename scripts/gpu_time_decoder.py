@@ -8,6 +8,8 @@ B = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 n = int(sys.argv[3]) if len(sys.argv) > 3 else 2048
 p = S.make_synthetic_decoder(L, seed=5)
 dec = DecoderWeights.from_params(p)
+import os
+dec.set_precision(os.environ.get('HM_PREC','f32'))
 lat = (0.07 * torch.randn(B, L)).float().cuda()
 pts4 = torch.zeros(B, n, 4); pts4[..., :3] = 0.04 * torch.randn(B, n, 3)
 pts4 = pts4.cuda()
