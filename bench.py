@@ -26,6 +26,7 @@ sys.path.insert(0, ROOT)
 FLOP_FWD = 3671040            # per decoder query, forward  (2 * (7 * 512^2 + 512))
 FLOP_FWD_BWD = 7342080        # forward + input-gradient backward
 PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
+PEAK_F16_MFMA_TFLOPS = 2500.0 # same table: "Peak BF16/FP16 MFMA ~2.5 PF dense"
 
 
 def cpu_baseline(params, cfg, inst_dict, kind, budget_s=15.0):
@@ -85,6 +86,9 @@ def main():
     ap.add_argument("--latent", type=int, default=256)
     ap.add_argument("--iters", type=int, default=200)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-exact", action="store_true", help="skip the extra exact-fp32 reference step")
+    ap.add_argument("--precision", default=os.environ.get("HM_PRECISION", "f16x3"), choices=["f32", "f16x3"],
+                    help="decoder GEMM arithmetic: exact fp32 MFMA or fp16 MFMA with hi/lo split operands")
     args = ap.parse_args()
 
     from hortimapping_amd import distributed as D
@@ -132,59 +136,84 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    lib.hm_workspace_profile(ws.handle, 1)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        allrec = step()
-    fence()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+    def measure(precision, steps, warmup):
+        """W untimed steps, then exactly K timed steps bracketed by barrier + synchronize; max over ranks."""
+        dec.set_precision(precision)
+        for _ in range(warmup):
+            step()
+        fence()
+        lib.hm_workspace_profile(ws.handle, 1)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            allrec = step()
+        fence()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt = float(tmax.item())
+        ms_tot, n_launch = ctypes.c_double(0), ctypes.c_longlong(0)
+        lib.hm_workspace_profile_read(ws.handle, ctypes.byref(ms_tot), ctypes.byref(n_launch))
+        lib.hm_workspace_profile(ws.handle, 0)
+        return dt, ms_tot.value, int(n_launch.value), allrec
 
-    ms_tot, n_launch = ctypes.c_double(0), ctypes.c_longlong(0)
-    lib.hm_workspace_profile_read(ws.handle, ctypes.byref(ms_tot), ctypes.byref(n_launch))
-    lib.hm_workspace_profile(ws.handle, 0)
+    n_s = int(pb.n_points.sum().item())
+    flops_per_launch = n_s * FLOP_FWD_BWD                 # SDF-term K1 launch: all B instances' surface points
+
+    def roofline(precision, ms_tot, n_launch):
+        avg_ms = ms_tot / max(1, n_launch)
+        achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12
+        peak = PEAK_F16_MFMA_TFLOPS if precision == "f16x3" else PEAK_F32_MFMA_TFLOPS
+        kname = "k_decoder_h<1,0>" if precision == "f16x3" else "k_decoder<1,0>"
+        traffic = None        # HBM/fabric bytes per launch from the committed PMC passes (same workload only)
+        tj = os.path.join(ROOT, "profiles", "r01_traffic.json")
+        if kind == "joint" and B == 64 and L == 256 and os.path.exists(tj):
+            traffic = json.load(open(tj)).get(precision, {}).get("bytes_per_launch")
+        r = {"bound": "mfma", "kernel": kname + " (SDF-term decoder forward + input-gradient backward)",
+             "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
+             "traffic": traffic, "launches": n_launch, "avg_launch_ms": round(avg_ms, 4),
+             "algorithmic_flop_per_launch": flops_per_launch}
+        if precision == "f16x3":
+            r["note"] = ("achieved counts ALGORITHMIC flop (dense fp32 decoder); the split-operand kernel issues 3 fp16 "
+                         "MFMA passes per product, so matrix-pipe utilisation is about 3 x 0.93 x frac")
+        return r
+
+    dt, ms_tot, n_launch, allrec = measure(args.precision, args.steps, args.warmup)
 
     if rank == 0:
         lat, T, it, st = D.unpack_records(allrec.cpu(), L)
         assert torch.isfinite(lat).all() and torch.isfinite(T).all(), "non-finite result"
         assert int(it.min()) == args.iters, f"iter_count {it.min()}..{it.max()} != {args.iters}"
-        value = n_total * args.steps / dt
-        n_s = int(pb.n_points.sum().item())
-        flops_per_launch = n_s * FLOP_FWD_BWD                     # SDF-term K1 launch: all B instances' surface points
-        avg_ms = ms_tot.value / max(1, n_launch.value)
-        achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12
-        traffic = None        # HBM/fabric bytes per launch from the committed PMC passes (same workload only)
-        tj = os.path.join(ROOT, "profiles", "r01_traffic.json")
-        if kind == "joint" and B == 64 and L == 256 and os.path.exists(tj):
-            traffic = json.load(open(tj))["bytes_per_launch"]
-        out = {
-            "metric": "fruit-instances/sec full optimisation (200 iters, 2048 pts)",
-            "value": round(value, 3), "unit": "instances/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {
-                "workload": ("c2_joint: 64 synthetic peppers per GPU, 256-dim latent, 8x512 DeepSDF decoder, "
-                             "joint latent + Sim(3) pose LM, 1024 surface pts + 1 frame x 64 rays x 16 samples "
-                             "(2048 decoder pts/iteration), 200 forced iterations" if kind == "joint" else
-                             "c2_sdf: 64 synthetic peppers per GPU, 256-dim latent, 8x512 DeepSDF decoder, shape-only "
-                             "LM (shape_opt_deepsdf), 2048 surface pts, 200 forced iterations"),
-                "instances_per_gpu": B, "latent_dim": L, "iterations": args.iters,
-                "parallelism": f"instances sharded over {world} GPU(s), one RCCL all-gather of results per step",
-            },
-            "roofline": {
-                "bound": "mfma", "kernel": "k_decoder<1,0> (SDF-term decoder forward + input-gradient backward)",
-                "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
-                "launches": int(n_launch.value), "avg_launch_ms": round(avg_ms, 4),
-                "algorithmic_flop_per_launch": flops_per_launch,
-            },
-        }
+    value = n_total * args.steps / dt
+    out = {
+        "metric": "fruit-instances/sec full optimisation (200 iters, 2048 pts)",
+        "value": round(value, 3), "unit": "instances/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None,
+        "dtype": ("f32 results via f16x3: fp16 MFMA with hi/lo split operands, fp32 accumulate, ~2^-22 relative "
+                  "(same error vs the fp64 oracle as exact fp32)" if args.precision == "f16x3" else "f32"),
+        "data": "synthetic",
+        "config": {
+            "workload": ("c2_joint: 64 synthetic peppers per GPU, 256-dim latent, 8x512 DeepSDF decoder, "
+                         "joint latent + Sim(3) pose LM, 1024 surface pts + 1 frame x 64 rays x 16 samples "
+                         "(2048 decoder pts/iteration), 200 forced iterations" if kind == "joint" else
+                         "c2_sdf: 64 synthetic peppers per GPU, 256-dim latent, 8x512 DeepSDF decoder, shape-only "
+                         "LM (shape_opt_deepsdf), 2048 surface pts, 200 forced iterations"),
+            "instances_per_gpu": B, "latent_dim": L, "iterations": args.iters, "precision": args.precision,
+            "parallelism": f"instances sharded over {world} GPU(s), one RCCL all-gather of results per step",
+        },
+        "roofline": roofline(args.precision, ms_tot, n_launch),
+    }
+    if args.precision != "f32" and not args.no_exact:
+        # the same job in exact fp32 arithmetic (v_mfma_f32_32x32x2_f32), one timed step, for reference
+        dt2, ms2, nl2, allrec2 = measure("f32", 1, 1)
+        if rank == 0:
+            l2, T2, _, _ = D.unpack_records(allrec2.cpu(), L)
+            out["exact_f32"] = {"value": round(n_total / dt2, 3), "unit": "instances/s", "steps": 1,
+                                "ms_per_step": round(dt2 * 1e3, 3), "roofline": roofline("f32", ms2, nl2),
+                                "max_abs_latent_diff_vs_primary": float((l2 - lat).abs().max()),
+                                "max_abs_T_diff_vs_primary": float((T2 - T).abs().max())}
+    if rank == 0:
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(params, cfg, dicts[0], kind)
         print(json.dumps(out), flush=True)

@@ -66,20 +66,28 @@ __global__ __launch_bounds__(64) void k_normal_eq(const NormalEqArgs a) {
     if (n <= 0 || nd <= 0) continue;
     const float scale = sg.weight / (float)nd;
     const float* base = sg.rows + (size_t)b * sg.inst_stride + (size_t)sg.row_offset * a.ldJ;
-    for (int r0 = 0; r0 < n; r0 += 8) {
-      float av[4], bv[4];
+    // software pipeline: the 12 loads of step r0+8 are issued before the 4 MFMAs of step r0
+    auto load_step = [&](int r0, float (&av)[4], float (&bv)[4]) {
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         const int row = r0 + 4 * h + t;
         const bool ok = row < n;
         const float* rp = base + (size_t)row * a.ldJ;
         const float res = ok ? rp[rcol] : 0.f;
-        const float cw = scale * huber_rho(res, sg.robust_th);
-        av[t] = (ok && okA) ? rp[colA] : 0.f;
-        bv[t] = (ok && okB) ? rp[colB] * cw : 0.f;
+        const float va = (ok && okA) ? rp[colA] : 0.f;
+        const float vb = (ok && okB) ? rp[colB] : 0.f;
+        av[t] = va;
+        bv[t] = vb * (scale * huber_rho(res, sg.robust_th));
       }
+    };
+    float av[4], bv[4], an[4], bn[4];
+    load_step(0, av, bv);
+    for (int r0 = 0; r0 < n; r0 += 8) {
+      if (r0 + 8 < n) load_step(r0 + 8, an, bn);
 #pragma unroll
       for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bv[t], acc, 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) { av[t] = an[t]; bv[t] = bn[t]; }
     }
   }
   float* H = a.Hext + (size_t)b * a.ldJ * a.ldJ;

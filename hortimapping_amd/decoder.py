@@ -61,6 +61,9 @@ class DecoderWeights:
         h = ctypes.c_void_p()
         _lib.check(lib.hm_decoder_create(L, Wp, bp, ctypes.byref(h)), "hm_decoder_create")
         self.handle = h
+        default = os.environ.get("HM_PRECISION", "")
+        if default:
+            self.set_precision(default)
 
     PRECISIONS = {"f32": 0, "f16x3": 1}
 

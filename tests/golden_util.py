@@ -51,7 +51,9 @@ def render_data_from_golden(g, as_torch=True):
     return rd
 
 
-def relmax(a, b):
+def relmax(a, b, floor=1e-30):
+    """max |a - b| relative to the largest reference magnitude (at least `floor`, the natural scale of the quantity,
+    so that a single near-zero value does not turn rounding noise into a large relative error)."""
     a = np.asarray(a, dtype=np.float64)
     b = np.asarray(b, dtype=np.float64)
-    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), floor))

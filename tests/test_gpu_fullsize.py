@@ -11,6 +11,16 @@ L, B = 256, 64
 _S = {}
 
 
+@pytest.fixture(params=["f32", "f16x3"], autouse=True, scope="module")
+def precision(request):
+    import os
+    os.environ["HM_PRECISION"] = request.param
+    _S.clear()
+    yield request.param
+    os.environ.pop("HM_PRECISION", None)
+    _S.clear()
+
+
 def setup():
     if _S:
         return _S
