@@ -86,7 +86,8 @@ __device__ __forceinline__ void gemm_loop(f32x16 (&acc)[2][2], const f32x4* __re
 template <int MODE, int TAG>
 __global__ __launch_bounds__(512, 2) void k_decoder(const DecodeArgs a) {
   __shared__ f32x4 xs[128 * TQ];   // 128 KiB: X[k/4][q] as float4 over k%4
-  __shared__ float sc[2048 + 128]; // partial sums of the VALU side paths
+  __shared__ float sc[2048 + 128];
+  __shared__ float bl[8 * HID];    // biases of the 8 forward stages (per-instance c0/c4 included), staged once per tile // partial sums of the VALU side paths
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -125,6 +126,12 @@ __global__ __launch_bounds__(512, 2) void k_decoder(const DecodeArgs a) {
   float y_keep = 0.f;                      // sdf of query = lane (every wave computes the same value)
   const float* cbias0 = a.c0 + (size_t)b * HID;
   const float* cbias4 = a.c4 + (size_t)b * HID;
+  // stage all forward biases in LDS: the epilogues then never wait on global memory
+  for (int i = tid; i < 8 * HID; i += 512) {
+    const StageDesc& sb = a.dec.st[i >> 9];
+    const float* src = sb.inst_bias == 1 ? cbias0 : (sb.inst_bias == 2 ? cbias4 : sb.bias);
+    bl[i] = src[i & (HID - 1)];
+  }
 
   constexpr int n_stage = MODE == 0 ? 8 : NSTAGE;
   for (int s = 0; s < n_stage; ++s) {
@@ -137,7 +144,10 @@ __global__ __launch_bounds__(512, 2) void k_decoder(const DecodeArgs a) {
 
     if (MODE == 1 && (epi == EPI_BWD4 || epi == EPI_BWD0)) {
       // xyz columns of lin4 / lin0, transposed: 3 x 512 dot per query on the VALU (rows of this wave's K slice)
-      const f32x4* wx = reinterpret_cast<const f32x4*>(epi == EPI_BWD4 ? a.dec.w4x : a.dec.w0x);
+      // stage the 512 x 4 xyz columns in LDS scratch (one 16-byte load per thread), then broadcast-read them
+      reinterpret_cast<f32x4*>(sc)[tid] = reinterpret_cast<const f32x4*>(epi == EPI_BWD4 ? a.dec.w4x : a.dec.w0x)[tid];
+      __syncthreads();
+      const f32x4* wx = reinterpret_cast<const f32x4*>(sc);
 #pragma unroll 4
       for (int g = 0; g < 16; ++g) {
         const f32x4 xv = xs[(16 * w + g) * TQ + lane];
@@ -166,7 +176,7 @@ __global__ __launch_bounds__(512, 2) void k_decoder(const DecodeArgs a) {
     __syncthreads();   // every wave is done reading X
 
     if (MODE == 0 || epi <= EPI_FWD7) {
-      const float* bias = sd.inst_bias == 1 ? cbias0 : (sd.inst_bias == 2 ? cbias4 : sd.bias);
+      const float* bias = bl + s * HID;
       uint2 mk = {0, 0};
 #pragma unroll
       for (int sl = 0; sl < 2; ++sl) {

@@ -10,6 +10,8 @@
 // order term and fp32 summation rounding.  Activations live in LDS as two fp16 planes [k/8][q][8] (2 x 64 KiB).
 // Tiling, register-resident ReLU masks, latent folding and the VALU side paths are those of hm_decoder.hip
 // (reference: deepsdf/networks/deep_sdf_decoder.py:75-110, wild_completion/utils.py:112-193, loss.py:229-241).
+#include <stdlib.h>
+
 #include "hm_common.h"
 #include "hm_internal.h"
 
@@ -33,6 +35,7 @@ struct DecodeArgsH {
   int B;
   int ldJ;
   int pose_dim;
+  long long* trace;    // optional [NSTAGE][4] shader-clock stamps of block 0 / wave 0 (perf analysis), or nullptr
 };
 
 constexpr float LO_SCALE = 2048.f;          // 2^11
@@ -58,41 +61,65 @@ __device__ __forceinline__ void split_store(f16x4* xh4, f16x4* xl4, int idx, con
   xl4[idx] = l;
 }
 
+// One K-step (16 k) of the split product for the two row blocks of this wave: 12 MFMAs.
+template <bool U0, bool U1>
+__device__ __forceinline__ void mfma_step_h(f32x16 (&acc)[2][2], const f16x8& a0h, const f16x8& a0l,
+                                            const f16x8& a1h, const f16x8& a1l, const f16x8& b0h,
+                                            const f16x8& b1h, const f16x8& b0l, const f16x8& b1l) {
+  const _Float16 cs = (_Float16)LO_UNSCALE;
+  if (U0) {
+    const f16x8 a0c = a0h * cs;
+    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, b0h, acc[0][0], 0, 0, 0);
+    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, b1h, acc[0][1], 0, 0, 0);
+    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0c, b0l, acc[0][0], 0, 0, 0);
+    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0c, b1l, acc[0][1], 0, 0, 0);
+    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0l, b0h, acc[0][0], 0, 0, 0);
+    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0l, b1h, acc[0][1], 0, 0, 0);
+  }
+  if (U1) {
+    const f16x8 a1c = a1h * cs;
+    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, b0h, acc[1][0], 0, 0, 0);
+    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, b1h, acc[1][1], 0, 0, 0);
+    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1c, b0l, acc[1][0], 0, 0, 0);
+    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1c, b1l, acc[1][1], 0, 0, 0);
+    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1l, b0h, acc[1][0], 0, 0, 0);
+    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1l, b1h, acc[1][1], 0, 0, 0);
+  }
+}
+
+// K loop, unrolled by two with two statically named operand sets (P, Q): the loads of step k+1 are issued before
+// the MFMAs of step k and land straight in the other set -- no register rotation, so hipcc emits counted waits
+// instead of draining vmcnt/lgkmcnt to zero every step (a rotating single-set version did exactly that and left
+// the matrix pipe idle two thirds of the time).
 template <bool U0, bool U1>
 __device__ __forceinline__ void gemm_loop_h(f32x16 (&acc)[2][2], const f16x8* __restrict__ wp0,
                                             const f16x8* __restrict__ wp1, int n_k16, const f16x8* xh,
                                             const f16x8* xl, int lane) {
   const int xo = (lane >> 5) * TQ + (lane & 31);
-  const _Float16 cs = (_Float16)LO_UNSCALE;
-  f16x8 a0h = {}, a0l = {}, a1h = {}, a1l = {};
-  if (U0) { a0h = wp0[0]; a0l = wp0[64]; }
-  if (U1) { a1h = wp1[0]; a1l = wp1[64]; }
-  for (int ks = 0; ks < n_k16; ++ks) {
-    const int kn = (ks + 1 < n_k16) ? ks + 1 : ks;
-    f16x8 n0h = a0h, n0l = a0l, n1h = a1h, n1l = a1l;
-    if (U0) { n0h = wp0[kn * 128]; n0l = wp0[kn * 128 + 64]; }
-    if (U1) { n1h = wp1[kn * 128]; n1l = wp1[kn * 128 + 64]; }
-    const f16x8 b0h = xh[ks * 2 * TQ + xo], b1h = xh[ks * 2 * TQ + xo + 32];
-    const f16x8 b0l = xl[ks * 2 * TQ + xo], b1l = xl[ks * 2 * TQ + xo + 32];
-    if (U0) {
-      const f16x8 a0c = a0h * cs;
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, b0h, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, b1h, acc[0][1], 0, 0, 0);
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0c, b0l, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0c, b1l, acc[0][1], 0, 0, 0);
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0l, b0h, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0l, b1h, acc[0][1], 0, 0, 0);
-    }
-    if (U1) {
-      const f16x8 a1c = a1h * cs;
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, b0h, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, b1h, acc[1][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1c, b0l, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1c, b1l, acc[1][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1l, b0h, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1l, b1h, acc[1][1], 0, 0, 0);
-    }
-    a0h = n0h; a0l = n0l; a1h = n1h; a1l = n1l;
+  f16x8 p0h = {}, p0l = {}, p1h = {}, p1l = {}, pb0h, pb1h, pb0l, pb1l;
+  f16x8 q0h = {}, q0l = {}, q1h = {}, q1l = {}, qb0h, qb1h, qb0l, qb1l;
+  if (U0) { p0h = wp0[0]; p0l = wp0[64]; }
+  if (U1) { p1h = wp1[0]; p1l = wp1[64]; }
+  pb0h = xh[xo]; pb1h = xh[xo + 32]; pb0l = xl[xo]; pb1l = xl[xo + 32];
+  for (int ks = 0; ks < n_k16; ks += 2) {
+    const bool has2 = ks + 1 < n_k16;
+    const int k1 = has2 ? ks + 1 : ks;
+    if (U0) { q0h = wp0[k1 * 128]; q0l = wp0[k1 * 128 + 64]; }
+    if (U1) { q1h = wp1[k1 * 128]; q1l = wp1[k1 * 128 + 64]; }
+    qb0h = xh[k1 * 2 * TQ + xo]; qb1h = xh[k1 * 2 * TQ + xo + 32];
+    qb0l = xl[k1 * 2 * TQ + xo]; qb1l = xl[k1 * 2 * TQ + xo + 32];
+    __builtin_amdgcn_sched_barrier(0);     // keep the prefetch ABOVE the MFMAs (hipcc otherwise sinks loads to their use)
+    mfma_step_h<U0, U1>(acc, p0h, p0l, p1h, p1l, pb0h, pb1h, pb0l, pb1l);
+    __builtin_amdgcn_sched_barrier(0);
+    if (!has2) break;
+    const int k2 = (ks + 2 < n_k16) ? ks + 2 : ks + 1;
+    if (U0) { p0h = wp0[k2 * 128]; p0l = wp0[k2 * 128 + 64]; }
+    if (U1) { p1h = wp1[k2 * 128]; p1l = wp1[k2 * 128 + 64]; }
+    pb0h = xh[k2 * 2 * TQ + xo]; pb1h = xh[k2 * 2 * TQ + xo + 32];
+    pb0l = xl[k2 * 2 * TQ + xo]; pb1l = xl[k2 * 2 * TQ + xo + 32];
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_step_h<U0, U1>(acc, q0h, q0l, q1h, q1l, qb0h, qb1h, qb0l, qb1l);
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 
@@ -112,6 +139,7 @@ __global__ __launch_bounds__(512, 2) void k_decoder_h(const DecodeArgsH a) {
   __shared__ f16x8 xh[64 * TQ];    // 64 KiB: hi plane  X[k/8][q][8]
   __shared__ f16x8 xl[64 * TQ];    // 64 KiB: lo plane (scaled by 2^11)
   __shared__ float sc[2048 + 128];
+  __shared__ float bl[8 * HID];    // biases of the 8 forward stages (per-instance c0/c4 included), staged once per tile
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -128,8 +156,6 @@ __global__ __launch_bounds__(512, 2) void k_decoder_h(const DecodeArgsH a) {
   const int qa = lane & 31;
   const int hi = lane >> 5;
   const f32x4* pts4 = reinterpret_cast<const f32x4*>(a.pts);
-  const f32x4 pA = pts4[qbase + qa];
-  const f32x4 pB = pts4[qbase + qa + 32];
   f16x4* xh4 = reinterpret_cast<f16x4*>(xh);
   f16x4* xl4 = reinterpret_cast<f16x4*>(xl);
 
@@ -147,11 +173,16 @@ __global__ __launch_bounds__(512, 2) void k_decoder_h(const DecodeArgsH a) {
   uint2 mk0 = {0, 0}, mk1 = {0, 0}, mk2 = {0, 0}, mk3 = {0, 0}, mk4 = {0, 0}, mk5 = {0, 0}, mk6 = {0, 0},
         mk7 = {0, 0};
   f32x16 acc[2][2];
-  f32x16 accz[2] = {zero16h(), zero16h()};
   float gx0 = 0.f, gx1 = 0.f, gx2 = 0.f;
   float y_keep = 0.f;
   const float* cbias0 = a.c0 + (size_t)b * HID;
   const float* cbias4 = a.c4 + (size_t)b * HID;
+  // stage all forward biases in LDS: the epilogues then never wait on global memory
+  for (int i = tid; i < 8 * HID; i += 512) {
+    const StageDesc& sb = a.dec.st[i >> 9];
+    const float* src = sb.inst_bias == 1 ? cbias0 : (sb.inst_bias == 2 ? cbias4 : sb.bias);
+    bl[i] = src[i & (HID - 1)];
+  }
 
   constexpr int n_stage = MODE == 0 ? 8 : NSTAGE;
   for (int s = 0; s < n_stage; ++s) {
@@ -163,9 +194,14 @@ __global__ __launch_bounds__(512, 2) void k_decoder_h(const DecodeArgsH a) {
     const bool u1 = (mb1 >= sd.mb_lo) && (mb1 < sd.mb_hi);
     const float us = sh.unscale;
     __syncthreads();
+    const bool tr = a.trace != nullptr && blockIdx.x == 0 && tid == 0;
+    if (tr) a.trace[s * 4 + 0] = clock64();
 
     if (MODE == 1 && (epi == EPI_BWD4 || epi == EPI_BWD0)) {
-      const f32x4* wx = reinterpret_cast<const f32x4*>(epi == EPI_BWD4 ? a.dec.w4x : a.dec.w0x);
+      // stage the 512 x 4 xyz columns in LDS scratch (one 16-byte load per thread), then broadcast-read them
+      reinterpret_cast<f32x4*>(sc)[tid] = reinterpret_cast<const f32x4*>(epi == EPI_BWD4 ? a.dec.w4x : a.dec.w0x)[tid];
+      __syncthreads();
+      const f32x4* wx = reinterpret_cast<const f32x4*>(sc);
 #pragma unroll 2
       for (int g = 0; g < 8; ++g) {
         float x[8];
@@ -181,12 +217,27 @@ __global__ __launch_bounds__(512, 2) void k_decoder_h(const DecodeArgsH a) {
     }
 
     acc[0][0] = zero16h(); acc[0][1] = zero16h();
-    if (MODE == 1 && epi == EPI_BWD0) {
-      // the kept latent rows are in true units; this stage accumulates at 2^shift
+    acc[1][0] = zero16h(); acc[1][1] = zero16h();
+    if (MODE == 1 && epi == EPI_BWD0 && u1) {
+      // d sdf/d z so far (lin4's transpose) was parked in this tile's J rows (true units); this stage accumulates at
+      // 2^shift, so seed the accumulators with it.  Parking it in L2 instead of 32 VGPRs across three stages is what
+      // keeps the K loop free of spills.
       const float rs = 1.f / us;
+      const int jz = (mb1 - mb_zx) * 32;
 #pragma unroll
-      for (int i = 0; i < 16; ++i) { acc[1][0][i] = accz[0][i] * rs; acc[1][1][i] = accz[1][i] * rs; }
-    } else { acc[1][0] = zero16h(); acc[1][1] = zero16h(); }
+      for (int nb = 0; nb < 2; ++nb) {
+        const int q = nb * 32 + qa;
+        if (q < cnt) {
+          const float* row = a.J + (qbase + q) * (size_t)a.ldJ;
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(row + jz + 8 * g + 4 * hi);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[1][nb][4 * g + j] = v[j] * rs;
+          }
+        }
+      }
+    }
 
     {
       const f16x8* wp = reinterpret_cast<const f16x8*>(sh.wp);
@@ -196,10 +247,12 @@ __global__ __launch_bounds__(512, 2) void k_decoder_h(const DecodeArgsH a) {
       else if (u0) gemm_loop_h<true, false>(acc, wp0, wp1, sh.n_k16, xh, xl, lane);
       else if (u1) gemm_loop_h<false, true>(acc, wp0, wp1, sh.n_k16, xh, xl, lane);
     }
+    if (tr) a.trace[s * 4 + 1] = clock64();
     __syncthreads();
+    if (tr) a.trace[s * 4 + 2] = clock64();
 
     if (MODE == 0 || epi <= EPI_FWD7) {
-      const float* bias = sd.inst_bias == 1 ? cbias0 : (sd.inst_bias == 2 ? cbias4 : sd.bias);
+      const float* bias = bl + s * HID;
       uint2 mk = {0, 0};
 #pragma unroll
       for (int sl = 0; sl < 2; ++sl) {
@@ -222,7 +275,7 @@ __global__ __launch_bounds__(512, 2) void k_decoder_h(const DecodeArgsH a) {
               v[j] = pos ? val : 0.f;
             }
             if (epi == EPI_FWD3) {
-              const f32x4 p = nb == 0 ? pA : pB;
+              const f32x4 p = pts4[qbase + nb * 32 + qa];
 #pragma unroll
               for (int j = 0; j < 4; ++j) {
                 const int r = f4 + j - m;
@@ -296,10 +349,23 @@ __global__ __launch_bounds__(512, 2) void k_decoder_h(const DecodeArgsH a) {
         const bool use = sl == 0 ? u0 : u1;
         if (!use) continue;
         const int mb = sl == 0 ? mb0 : mb1;
-        if (epi == EPI_BWD4 && mb >= mb_zx) {
+        if (epi == EPI_BWD4 && mb >= mb_zx) {      // latent rows: park in J (same thread re-reads them in BWD0)
           if (sl == 1) {
+            const int jz = (mb1 - mb_zx) * 32;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) { accz[0][i] = acc[1][0][i] * us; accz[1][i] = acc[1][1][i] * us; }
+            for (int nb = 0; nb < 2; ++nb) {
+              const int q = nb * 32 + qa;
+              if (q < cnt) {
+                float* row = a.J + (qbase + q) * (size_t)a.ldJ;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                  f32x4 v;
+#pragma unroll
+                  for (int j = 0; j < 4; ++j) v[j] = acc[1][nb][4 * g + j] * us;
+                  *reinterpret_cast<f32x4*>(row + jz + 8 * g + 4 * hi) = v;
+                }
+              }
+            }
           }
           continue;
         }
@@ -338,6 +404,7 @@ __global__ __launch_bounds__(512, 2) void k_decoder_h(const DecodeArgsH a) {
     }
   }
 
+  if (a.trace != nullptr && blockIdx.x == 0 && tid == 0) a.trace[n_stage * 4] = clock64();
   if (MODE == 0) return;
   sc[(w * 4 + 0) * 64 + lane] = gx0;
   sc[(w * 4 + 1) * 64 + lane] = gx1;
@@ -366,6 +433,9 @@ __global__ __launch_bounds__(512, 2) void k_decoder_h(const DecodeArgsH a) {
 
 }  // namespace
 
+static long long* g_trace = nullptr;
+extern "C" void hm_debug_set_trace(long long* d_buf) { g_trace = d_buf; }
+
 namespace hm {
 
 int launch_decoder_h(const hm_decoder_s* dec, int B, const float* d_pts, const int* d_nq, const int* d_active,
@@ -375,6 +445,7 @@ int launch_decoder_h(const hm_decoder_s* dec, int B, const float* d_pts, const i
   a.dec = dec->dev;
   a.pts = d_pts; a.n_q = d_nq; a.active = d_active; a.c0 = d_c0; a.c4 = d_c4;
   a.y = d_y; a.J = d_J; a.n_stride = n_stride; a.B = B; a.ldJ = ldJ; a.pose_dim = pose_dim;
+  a.trace = g_trace;
   const int grid = B * (n_stride / TQ);
   if (grid == 0) return 0;
   if (mode == 0) hipLaunchKernelGGL((k_decoder_h<0, 0>), dim3(grid), dim3(512), 0, stream, a);

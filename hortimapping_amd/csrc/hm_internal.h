@@ -25,6 +25,7 @@ struct RowSegment {
 
 struct SolveArgs {
   const float* Hext;       // [B][ldJ][ldJ]
+  float* Lfac;             // [B][288][288] scratch: Cholesky factor panels
   float* latent;           // [B][ld_latent]
   float* T_ow;             // [B][16]
   const int* pose_known;   // [B] or nullptr

@@ -29,6 +29,7 @@ struct hm_workspace_s {
   float *c0, *c4;
   float *ptsS, *JS, *yS;
   float* Hext;
+  float* Lfac;
   int *active, *nS_dummy;
   RenderBuffers rb;
   // optional timing of the dominant launch (SDF-term K1) with HIP events on the caller's stream
@@ -62,6 +63,7 @@ void carve(hm_workspace_s* w, Carver& c) {
   w->JS = c.take<float>((size_t)B * w->nS_stride * w->ldJ);
   w->yS = c.take<float>((size_t)B * w->nS_stride);
   w->Hext = c.take<float>((size_t)B * w->ldJ * w->ldJ);
+  w->Lfac = c.take<float>((size_t)B * 288 * 288);
   w->active = c.take<int>(B);
   RenderBuffers& rb = w->rb;
   rb.frame = c.take<float>((size_t)B * F * 16);
@@ -272,7 +274,7 @@ extern "C" int hm_optimize_batch(hm_workspace_s* ws, const hm_opt_cfg* cfg, cons
 
     SolveArgs sa;
     memset(&sa, 0, sizeof(sa));
-    sa.Hext = ws->Hext; sa.latent = bt->d_latent; sa.T_ow = bt->d_T_ow;
+    sa.Hext = ws->Hext; sa.Lfac = ws->Lfac; sa.latent = bt->d_latent; sa.T_ow = bt->d_T_ow;
     sa.pose_known = bt->d_pose_known; sa.V = mode == 0 ? rb.V : nullptr;
     sa.active = ws->active; sa.iter_count = bt->d_iter_count; sa.status = bt->d_status; sa.cur_scale = nullptr;
     sa.dbg_A = dbg ? dbg->d_A : nullptr; sa.dbg_b = dbg ? dbg->d_b : nullptr; sa.dbg_delta = dbg ? dbg->d_delta : nullptr;

@@ -19,7 +19,8 @@ using namespace hm;
 namespace {
 
 constexpr int MAX_E = MAX_L + 7;
-constexpr int NT = 1024;
+constexpr int NT = 512;      // 8 waves: up to 6 of the 45 lower-triangular 32x32 blocks per wave
+constexpr int NSLOT = 6;
 
 __device__ __forceinline__ int tri(int i, int j) { return i * (i + 1) / 2 + j; }   // i >= j
 
@@ -89,95 +90,98 @@ __device__ __forceinline__ double wave_sum(double v) {
 }  // namespace
 
 constexpr int NBK = (MAX_E + 31) / 32;   // 32-wide blocks of the unknown vector (9 for E <= 263)
+constexpr int PS = 36;                    // padded row stride of a 32x32 panel block in LDS (16-byte aligned rows)
+constexpr int LGS = NBK * 32;             // row stride of the factor in global scratch
 
-// Blocked triangular solves on the packed factor in LDS.  `rv` holds the right-hand side on entry and the solution
-// on exit.  Diagonal 32x32 blocks are solved by one wavefront with lane-parallel column updates (no reductions on
-// the serial chain); the off-diagonal updates are spread over the whole workgroup.
+__device__ __forceinline__ float rdlane(float v, int l) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+}
+
+// Triangular solves L y = r, L^T x = y on the packed factor in LDS whose DIAGONAL 32x32 blocks have been replaced by
+// their inverses: every block step is a 32x32 mat-vec (no serial chain) plus a workgroup-wide off-diagonal update.
+// `rv` holds the right-hand side on entry and the solution on exit.
 __device__ void solve_packed(const float* Lp, float* rv, int E, int tid) {
   const int lane = tid & 63, wv = tid >> 6;
   const int nblk = (E + 31) / 32;
-  // forward: L y = r
-  for (int bb = 0; bb < nblk; ++bb) {
+  for (int bb = 0; bb < nblk; ++bb) {                      // forward
     const int base = bb * 32;
     if (wv == 0) {
       const int i = base + (lane & 31);
-      const bool ok = i < E;
-      float ri = ok ? rv[i] : 0.f;
-      float lrow[32];
-#pragma unroll
-      for (int jj = 0; jj < 32; ++jj) lrow[jj] = (ok && base + jj <= i) ? Lp[tri(i, base + jj)] : 1.f;
-#pragma unroll
-      for (int jj = 0; jj < 32; ++jj) {
-        const float num = __shfl(ri, jj);
-        const float ljj = __shfl(lrow[jj], jj);
-        const float yj = num / ljj;
-        if ((lane & 31) == jj) ri = yj;
-        else if ((lane & 31) > jj) ri -= lrow[jj] * yj;
+      float s = 0.f;
+      if (i < E) {
+        const float* lr = Lp + tri(i, base);
+#pragma unroll 8
+        for (int k = 0; k < 32; ++k) s = fmaf((k <= (lane & 31)) ? lr[k] : 0.f, rv[base + k], s);
       }
-      if (lane < 32 && ok) rv[i] = ri;
+      __builtin_amdgcn_wave_barrier();
+      if (lane < 32 && i < E) rv[i] = s;
     }
     __syncthreads();
+    const int hi = (base + 32 < E) ? 32 : E - base;
     for (int i = base + 32 + tid; i < E; i += NT) {
       float s = 0.f;
       const float* lr = Lp + tri(i, base);
 #pragma unroll 8
-      for (int kk = 0; kk < 32; ++kk) s = fmaf(lr[kk], rv[base + kk], s);
+      for (int kk = 0; kk < 32; ++kk) s = fmaf(kk < hi ? lr[kk] : 0.f, rv[base + (kk < hi ? kk : 0)], s);
       rv[i] -= s;
     }
     __syncthreads();
   }
-  // backward: L^T x = y
-  for (int bb = nblk - 1; bb >= 0; --bb) {
+  for (int bb = nblk - 1; bb >= 0; --bb) {                 // backward (transposed)
     const int base = bb * 32;
+    const int hi = (base + 32 < E) ? 32 : E - base;
     if (wv == 0) {
       const int j = base + (lane & 31);
-      const bool ok = j < E;
-      float sj = ok ? rv[j] : 0.f;
-      for (int ii = 31; ii >= 0; --ii) {
-        const int i = base + ii;
-        if (i >= E) continue;
-        const float lii = Lp[tri(i, i)];
-        const float xi = __shfl(sj, ii) / lii;
-        const float lij = (ok && j < i) ? Lp[tri(i, j)] : 0.f;
-        if ((lane & 31) == ii) sj = xi;
-        else if ((lane & 31) < ii) sj -= lij * xi;
+      float s = 0.f;
+      if (j < E) {
+#pragma unroll 8
+        for (int ii = 0; ii < 32; ++ii) {
+          const bool use = ii >= (lane & 31) && ii < hi;
+          s = fmaf(use ? Lp[tri(base + ii, j)] : 0.f, rv[base + (ii < hi ? ii : 0)], s);
+        }
       }
-      if (lane < 32 && ok) rv[j] = sj;
+      __builtin_amdgcn_wave_barrier();
+      if (lane < 32 && j < E) rv[j] = s;
     }
     __syncthreads();
-    const int hi = (base + 32 < E) ? base + 32 : E;
     for (int j = tid; j < base; j += NT) {
       float s = 0.f;
-      for (int i = base; i < hi; ++i) s = fmaf(Lp[tri(i, j)], rv[i], s);
+#pragma unroll 8
+      for (int ii = 0; ii < 32; ++ii) s = fmaf(ii < hi ? Lp[tri(base + (ii < hi ? ii : 0), j)] : 0.f, rv[base + (ii < hi ? ii : 0)], s);
       rv[j] -= s;
     }
     __syncthreads();
   }
 }
 
+__device__ long long* g_k5_trace = nullptr;
+
 __global__ __launch_bounds__(NT) void k_solve_update(const SolveArgs a) {
-  __shared__ float Lp[MAX_E * (MAX_E + 1) / 2];   // packed lower-triangular Cholesky factor (<= 139 KiB)
-  __shared__ float cj[NBK * 32];
+  // one LDS array, two lives: the 32-column panel [NBK][32][PS] during the factorisation, then the packed factor
+  __shared__ float smem[MAX_E * (MAX_E + 1) / 2];
   __shared__ float bvec[NBK * 32];
   __shared__ float xvec[NBK * 32];
   __shared__ float rv[NBK * 32];
   __shared__ float diagA[NBK * 32];
   __shared__ float red[NT / 64];
   __shared__ float red2[NT / 64];
-  __shared__ float sh_piv;
   __shared__ int flag;
 
   const int b = blockIdx.x;
   const int tid = threadIdx.x;
   if (a.active[b] == 0) return;
+  const bool trc = g_k5_trace != nullptr && b == 0 && tid == 0;
+  if (trc) g_k5_trace[0] = clock64();
   if (a.V != nullptr && a.V[b] <= 0) {           // optimizer.py:139-141
     if (tid == 0) { a.active[b] = 0; a.status[b] |= HM_STATUS_INVALID; }
     return;
   }
   const int L = a.L, P = a.P, E = L + P, ld = a.ldJ;
   const float* H = a.Hext + (size_t)b * ld * ld;
+  float* Lg = a.Lfac + (size_t)b * LGS * LGS;
   float* z = a.latent + (size_t)b * a.ld_latent;
   const int lane = tid & 63, wv = tid >> 6;
+  const int nblk = (E + 31) / 32;
 
   // ---- assemble (optimizer.py:200-231) ----
   for (int i = tid; i < E; i += NT) {
@@ -206,93 +210,176 @@ __global__ __launch_bounds__(NT) void k_solve_update(const SolveArgs a) {
     }
   }
   __syncthreads();
-
-  // ---- register-resident right-looking Cholesky: thread (ti, tk) owns A[32 bi + ti][32 bk + tk], bk <= bi ----
-  const int tk = tid & 31, ti = tid >> 5;
-  float A[NBK][NBK];
-#pragma unroll
-  for (int bi = 0; bi < NBK; ++bi)
-#pragma unroll
-    for (int bk = 0; bk <= bi; ++bk) {
-      const int i = bi * 32 + ti, k = bk * 32 + tk;
-      float v = 0.f;
-      if (i < E && k <= i) v = (i == k) ? diagA[i] : H[(size_t)i * ld + k];
-      A[bi][bk] = v;
-    }
   if (a.dbg_A != nullptr) {
     float* Ad = a.dbg_A + (size_t)b * ld * ld;
-#pragma unroll
-    for (int bi = 0; bi < NBK; ++bi)
-#pragma unroll
-      for (int bk = 0; bk <= bi; ++bk) {
-        const int i = bi * 32 + ti, k = bk * 32 + tk;
-        if (i < E && k <= i) Ad[(size_t)i * ld + k] = A[bi][bk];
-      }
+    for (int i = tid >> 5; i < E; i += NT / 32)
+      for (int k = tid & 31; k <= i; k += 32) Ad[(size_t)i * ld + k] = (i == k) ? diagA[i] : H[(size_t)i * ld + k];
   }
   if (a.dbg_b != nullptr)
     for (int i = tid; i < E; i += NT) a.dbg_b[(size_t)b * ld + i] = bvec[i];
+  if (trc) g_k5_trace[1] = clock64();
 
+  // ---- blocked right-looking Cholesky, 32-column panels, trailing update on the fp32 matrix cores ----
+  // Wave w owns the lower-triangular 32x32 blocks p = w, w+8, ... (p = bi(bi+1)/2 + bk) in MFMA C layout.
+  const int cc = lane & 31, hh = lane >> 5;
+  f32x16 blk[NSLOT];
+  int obi[NSLOT], obk[NSLOT];
 #pragma unroll
-  for (int bj = 0; bj < NBK; ++bj) {
-    for (int tj = 0; tj < 32; ++tj) {
-      const int j = bj * 32 + tj;
-      if (j >= E) break;
-      if (ti == tj && tk == tj) sh_piv = A[bj][bj];
-      __syncthreads();
-      const float piv = sh_piv;
-      if (!(piv > 0.f)) flag = 1;
-      const float d = sqrtf(piv);
-      const float inv = 1.f / d;
-      if (tk == tj) {
+  for (int sl = 0; sl < NSLOT; ++sl) {
+    const int p = wv + (NT / 64) * sl;
+    int bi = 0;
+    while ((bi + 1) * (bi + 2) / 2 <= p) ++bi;
+    const int bk = p - bi * (bi + 1) / 2;
+    obi[sl] = bi < nblk ? bi : -1;
+    obk[sl] = bk;
 #pragma unroll
-        for (int bi = bj; bi < NBK; ++bi) {
-          const int i = bi * 32 + ti;
-          if (i > j && i < E) {
-            const float l = A[bi][bj] * inv;
-            A[bi][bj] = l;
-            cj[i] = l;
-            Lp[tri(i, j)] = l;
-          } else if (i == j) {
-            Lp[tri(j, j)] = d;
-          }
-        }
-      }
-      __syncthreads();
-      float ci[NBK], ck[NBK];
-#pragma unroll
-      for (int bb = bj; bb < NBK; ++bb) { ci[bb] = cj[bb * 32 + ti]; ck[bb] = cj[bb * 32 + tk]; }
-#pragma unroll
-      for (int bi = bj; bi < NBK; ++bi)
-#pragma unroll
-        for (int bk = bj; bk <= bi; ++bk) {
-          const int i = bi * 32 + ti, k = bk * 32 + tk;
-          if (k > j && k <= i && i < E) A[bi][bk] = fmaf(-ci[bi], ck[bk], A[bi][bk]);
-        }
+    for (int r = 0; r < 16; ++r) {
+      const int i = bi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh, k = bk * 32 + cc;
+      float v = (i == k) ? 1.f : 0.f;                           // padding: identity
+      if (bi < nblk && i < E && k < E) v = (i == k) ? diagA[i] : (k < i ? H[(size_t)i * ld + k] : H[(size_t)k * ld + i]);
+      blk[sl][r] = v;
     }
   }
-  __syncthreads();
+  float* Pn = smem;                                             // panel: Pn[(bi * 32 + row) * PS + col]
+  for (int bj = 0; bj < nblk; ++bj) {
+    // 1. owners of block column bj publish their blocks
+#pragma unroll
+    for (int sl = 0; sl < NSLOT; ++sl)
+      if (obi[sl] >= 0 && obk[sl] == bj) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          Pn[(obi[sl] * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh) * PS + cc] = blk[sl][r];
+      }
+    __syncthreads();
+    // 2. diagonal block: in-wave Cholesky, lane = row, columns in registers, broadcasts by v_readlane
+    if (wv == 0) {
+      float ar[32];
+      const float* src = Pn + (bj * 32 + cc) * PS;
+#pragma unroll
+      for (int k = 0; k < 32; ++k) ar[k] = src[k];
+      bool bad = false;
+#pragma unroll
+      for (int k = 0; k < 32; ++k) {
+        const float piv = rdlane(ar[k], k);
+        bad |= !(piv > 0.f);
+        const float d = sqrtf(piv);
+        const float inv = 1.f / d;
+        ar[k] = (cc == k) ? d : ar[k] * inv;
+#pragma unroll
+        for (int j = k + 1; j < 32; ++j) ar[j] = fmaf(-ar[k], rdlane(ar[k], j), ar[j]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (bad) flag = 1;
+      if (lane < 32) {
+        float* dst = Pn + (bj * 32 + cc) * PS;
+#pragma unroll
+        for (int k = 0; k < 32; ++k) dst[k] = (k <= cc) ? ar[k] : 0.f;
+      }
+    }
+    __syncthreads();
+    // 3. panel below the diagonal block: row-wise forward substitution  x L11^T = a
+    {
+      const int nrow = (nblk - 1 - bj) * 32;
+      const float* L11 = Pn + bj * 32 * PS;
+      for (int t = tid; t < nrow; t += NT) {
+        float* row = Pn + ((bj + 1) * 32 + t) * PS;
+        float x[32];
+#pragma unroll
+        for (int k = 0; k < 32; ++k) x[k] = row[k];
+#pragma unroll
+        for (int k = 0; k < 32; ++k) {
+          float sacc = x[k];
+#pragma unroll
+          for (int m2 = 0; m2 < k; ++m2) sacc = fmaf(-x[m2], L11[k * PS + m2], sacc);
+          x[k] = sacc / L11[k * PS + k];
+          __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int k = 0; k < 32; ++k) row[k] = x[k];
+      }
+    }
+    __syncthreads();
+    // 4. trailing update  A22 -= L21 L21^T  on the matrix cores, and the finished panel goes to global scratch
+#pragma unroll
+    for (int sl = 0; sl < NSLOT; ++sl)
+      if (obi[sl] >= 0 && obk[sl] > bj) {
+        const float* pa = Pn + (obi[sl] * 32 + cc) * PS + 4 * hh;
+        const float* pb = Pn + (obk[sl] * 32 + cc) * PS + 4 * hh;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 av = *reinterpret_cast<const f32x4*>(pa + 8 * g);
+          const f32x4 bv = *reinterpret_cast<const f32x4*>(pb + 8 * g);
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+            blk[sl] = __builtin_amdgcn_mfma_f32_32x32x2f32(-av[t], bv[t], blk[sl], 0, 0, 0);
+        }
+      }
+    {
+      const int nel = (nblk - bj) * 32 * 32;
+      for (int e = tid; e < nel; e += NT) {
+        const int r = e >> 5, k = e & 31;
+        Lg[(size_t)(bj * 32 + r) * LGS + bj * 32 + k] = Pn[(bj * 32 + r) * PS + k];
+      }
+    }
+    __syncthreads();
+  }
   if (flag) {
     if (tid == 0) { a.active[b] = 0; a.status[b] |= HM_STATUS_SOLVE_FAILED; }
     return;
   }
+  if (trc) g_k5_trace[2] = clock64();
+  // packed factor into LDS (the panel area is dead now), then invert its diagonal blocks in place
+  __threadfence_block();
+  float* Lp = smem;
+  for (int i = tid >> 5; i < E; i += NT / 32)
+    for (int k = tid & 31; k <= i; k += 32) Lp[tri(i, k)] = Lg[(size_t)i * LGS + k];
+  __syncthreads();
+  for (int bb = wv; bb < nblk; bb += NT / 64) {
+    // column `cc` of inverse(L11): x[k] = Linv[k][cc], forward substitution on e_cc with broadcast reads of L11
+    const int base = bb * 32;
+    float x[32];
+#pragma unroll
+    for (int k = 0; k < 32; ++k) {
+      const int i = base + k;
+      float sacc = (k == cc) ? 1.f : 0.f;
+      if (i < E) {
+#pragma unroll
+        for (int m2 = 0; m2 < k; ++m2) sacc = fmaf(-x[m2], Lp[tri(i, base + m2)], sacc);
+        x[k] = (k >= cc) ? sacc / Lp[tri(i, i)] : 0.f;
+      } else {
+        x[k] = 0.f;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (lane < 32) {
+#pragma unroll
+      for (int k = 0; k < 32; ++k)
+        if (k >= cc && base + k < E && base + cc < E) Lp[tri(base + k, base + cc)] = x[k];
+    }
+  }
+  __syncthreads();
 
   // ---- solve L L^T x = b (fp32), then one refinement step with an fp64 residual from the fp32 system ----
   for (int i = tid; i < NBK * 32; i += NT) { rv[i] = i < E ? bvec[i] : 0.f; xvec[i] = 0.f; }
   __syncthreads();
   solve_packed(Lp, rv, E, tid);
+  if (trc) g_k5_trace[3] = clock64();
   for (int i = tid; i < E; i += NT) xvec[i] = rv[i];
   __syncthreads();
   for (int i = wv; i < E; i += NT / 64) {
-    double s = 0.0;
+    double sd = 0.0;
     for (int k = lane; k < E; k += 64) {
       const float aik = (k == i) ? diagA[i] : (k < i ? H[(size_t)i * ld + k] : H[(size_t)k * ld + i]);
-      s += (double)aik * (double)xvec[k];
+      sd += (double)aik * (double)xvec[k];
     }
-    s = wave_sum(s);
-    if (lane == 0) rv[i] = (float)((double)bvec[i] - s);
+    sd = wave_sum(sd);
+    if (lane == 0) rv[i] = (float)((double)bvec[i] - sd);
   }
   __syncthreads();
+  if (trc) g_k5_trace[4] = clock64();
   solve_packed(Lp, rv, E, tid);
+  if (trc) g_k5_trace[5] = clock64();
   for (int i = tid; i < E; i += NT) xvec[i] += rv[i];
   __syncthreads();
   if (a.dbg_delta != nullptr)
@@ -356,6 +443,10 @@ __global__ __launch_bounds__(NT) void k_solve_update(const SolveArgs a) {
     else if (a.iter == a.max_iter - 1) st = HM_STATUS_MAX_ITER;       // :289
     if (st != 0) { a.status[b] |= st; a.active[b] = 0; }
   }
+}
+
+extern "C" void hm_debug_set_k5_trace(long long* d_buf) {
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_k5_trace), &d_buf, sizeof(d_buf));
 }
 
 namespace hm {

@@ -11,6 +11,7 @@ from collections import defaultdict
 
 
 def short(name):
+    name = name.replace("(anonymous namespace)::", "").replace("void ", "")
     return name.split("(")[0][-60:]
 
 
