@@ -87,40 +87,52 @@ __device__ __forceinline__ void mfma_step_h(f32x16 (&acc)[2][2], const f16x8& a0
   }
 }
 
-// K loop, unrolled by two with two statically named operand sets (P, Q): the loads of step k+1 are issued before
-// the MFMAs of step k and land straight in the other set -- no register rotation, so hipcc emits counted waits
-// instead of draining vmcnt/lgkmcnt to zero every step (a rotating single-set version did exactly that and left
-// the matrix pipe idle two thirds of the time).
+// K loop.  Weights (A, from L2) are fetched TWO K-steps ahead into a ring of three statically named register sets,
+// activations (B, from LDS) one step ahead into a ring of two; the loop is unrolled by six so every set has a fixed
+// name (no register rotation => hipcc emits counted waits instead of draining vmcnt/lgkmcnt each step), and
+// sched_barriers keep each prefetch above the MFMAs it overlaps (hipcc otherwise sinks loads to their first use).
+struct ASet { f16x8 h0, l0, h1, l1; };
+struct BSet { f16x8 h0, h1, l0, l1; };
+
+template <bool U0, bool U1>
+__device__ __forceinline__ void load_a(ASet& a, const f16x8* __restrict__ wp0, const f16x8* __restrict__ wp1, int k) {
+  if (U0) { a.h0 = wp0[k * 128]; a.l0 = wp0[k * 128 + 64]; }
+  if (U1) { a.h1 = wp1[k * 128]; a.l1 = wp1[k * 128 + 64]; }
+}
+
+__device__ __forceinline__ void load_b(BSet& b, const f16x8* xh, const f16x8* xl, int k, int xo) {
+  b.h0 = xh[k * 2 * TQ + xo]; b.h1 = xh[k * 2 * TQ + xo + 32];
+  b.l0 = xl[k * 2 * TQ + xo]; b.l1 = xl[k * 2 * TQ + xo + 32];
+}
+
 template <bool U0, bool U1>
 __device__ __forceinline__ void gemm_loop_h(f32x16 (&acc)[2][2], const f16x8* __restrict__ wp0,
                                             const f16x8* __restrict__ wp1, int n_k16, const f16x8* xh,
                                             const f16x8* xl, int lane) {
   const int xo = (lane >> 5) * TQ + (lane & 31);
-  f16x8 p0h = {}, p0l = {}, p1h = {}, p1l = {}, pb0h, pb1h, pb0l, pb1l;
-  f16x8 q0h = {}, q0l = {}, q1h = {}, q1l = {}, qb0h, qb1h, qb0l, qb1l;
-  if (U0) { p0h = wp0[0]; p0l = wp0[64]; }
-  if (U1) { p1h = wp1[0]; p1l = wp1[64]; }
-  pb0h = xh[xo]; pb1h = xh[xo + 32]; pb0l = xl[xo]; pb1l = xl[xo + 32];
-  for (int ks = 0; ks < n_k16; ks += 2) {
-    const bool has2 = ks + 1 < n_k16;
-    const int k1 = has2 ? ks + 1 : ks;
-    if (U0) { q0h = wp0[k1 * 128]; q0l = wp0[k1 * 128 + 64]; }
-    if (U1) { q1h = wp1[k1 * 128]; q1l = wp1[k1 * 128 + 64]; }
-    qb0h = xh[k1 * 2 * TQ + xo]; qb1h = xh[k1 * 2 * TQ + xo + 32];
-    qb0l = xl[k1 * 2 * TQ + xo]; qb1l = xl[k1 * 2 * TQ + xo + 32];
-    __builtin_amdgcn_sched_barrier(0);     // keep the prefetch ABOVE the MFMAs (hipcc otherwise sinks loads to their use)
-    mfma_step_h<U0, U1>(acc, p0h, p0l, p1h, p1l, pb0h, pb1h, pb0l, pb1l);
-    __builtin_amdgcn_sched_barrier(0);
-    if (!has2) break;
-    const int k2 = (ks + 2 < n_k16) ? ks + 2 : ks + 1;
-    if (U0) { p0h = wp0[k2 * 128]; p0l = wp0[k2 * 128 + 64]; }
-    if (U1) { p1h = wp1[k2 * 128]; p1l = wp1[k2 * 128 + 64]; }
-    pb0h = xh[k2 * 2 * TQ + xo]; pb1h = xh[k2 * 2 * TQ + xo + 32];
-    pb0l = xl[k2 * 2 * TQ + xo]; pb1l = xl[k2 * 2 * TQ + xo + 32];
-    __builtin_amdgcn_sched_barrier(0);
-    mfma_step_h<U0, U1>(acc, q0h, q0l, q1h, q1l, qb0h, qb1h, qb0l, qb1l);
-    __builtin_amdgcn_sched_barrier(0);
+  const int last = n_k16 - 1;
+  ASet a0 = {}, a1 = {}, a2 = {};
+  BSet b0, b1;
+  load_a<U0, U1>(a0, wp0, wp1, 0);
+  load_a<U0, U1>(a1, wp0, wp1, last < 1 ? last : 1);
+  load_b(b0, xh, xl, 0, xo);
+#define HM_STEP(AS, BS, ANEXT, BNEXT, I)                                                         \
+  if (ks + (I) < n_k16) {                                                                        \
+    load_a<U0, U1>(ANEXT, wp0, wp1, (ks + (I) + 2 < n_k16) ? ks + (I) + 2 : last);               \
+    load_b(BNEXT, xh, xl, (ks + (I) + 1 < n_k16) ? ks + (I) + 1 : last, xo);                     \
+    __builtin_amdgcn_sched_barrier(0);                                                           \
+    mfma_step_h<U0, U1>(acc, AS.h0, AS.l0, AS.h1, AS.l1, BS.h0, BS.h1, BS.l0, BS.l1);            \
+    __builtin_amdgcn_sched_barrier(0);                                                           \
   }
+  for (int ks = 0; ks < n_k16; ks += 6) {
+    HM_STEP(a0, b0, a2, b1, 0)
+    HM_STEP(a1, b1, a0, b0, 1)
+    HM_STEP(a2, b0, a1, b1, 2)
+    HM_STEP(a0, b1, a2, b0, 3)
+    HM_STEP(a1, b0, a0, b1, 4)
+    HM_STEP(a2, b1, a1, b0, 5)
+  }
+#undef HM_STEP
 }
 
 // X[k][q] as float for k = 8*grp + j (VALU side paths)

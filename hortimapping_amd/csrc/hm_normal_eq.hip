@@ -7,8 +7,9 @@
 // The row weight is c_i = weight * rho_i / count with rho_i the squared Huber weight of r_i
 // (wild_completion/utils.py:327-358) when the robust kernel is on for that term, else 1.
 //
-// One wavefront owns one lower-triangular 32x32 block pair of one instance and walks all rows of up to three
-// row segments (SDF rows, depth-render rows, mask-render rows); the blockIdx -> (instance, pair) map keeps all
+// One 4-wave workgroup owns one lower-triangular 32x32 block pair of one instance; the waves split the rows of up
+// to three row segments round-robin in groups of 8 and their partial blocks are summed in a fixed order through LDS.
+// Row segments: (SDF rows, depth-render rows, mask-render rows); the blockIdx -> (instance, pair) map keeps all
 // pairs of an instance on one XCD so that the instance's rows are fetched from HBM once and re-read from that
 // XCD's L2.  Fixed summation order => bitwise reproducible.
 #include "hm_common.h"
@@ -34,7 +35,10 @@ __device__ __forceinline__ float huber_rho(float r, float th) {
   return (2.f * th * a - th * th) / (a * a);
 }
 
-__global__ __launch_bounds__(64) void k_normal_eq(const NormalEqArgs a) {
+constexpr int KSPLIT = 4;   // waves per block pair: each takes every 4th group of 8 rows, partials reduced through LDS
+
+__global__ __launch_bounds__(64 * KSPLIT) void k_normal_eq(const NormalEqArgs a) {
+  __shared__ float part[KSPLIT - 1][16][64];
   // XCD-aware decomposition: blockIdx % 8 selects the XCD (observed dispatch rule); all pairs of an instance share it
   const int npair = a.nblk * (a.nblk + 1) / 2;
   const int xcd = blockIdx.x & 7;
@@ -49,7 +53,8 @@ __global__ __launch_bounds__(64) void k_normal_eq(const NormalEqArgs a) {
   while ((bi + 1) * (bi + 2) / 2 <= pair) ++bi;
   const int bj = pair - bi * (bi + 1) / 2;
 
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int ws = threadIdx.x >> 6;           // K-split index of this wave
   const int c = lane & 31, h = lane >> 5;
   const int colA = bi * 32 + c, colB = bj * 32 + c;
   const bool okA = colA < a.ldJ, okB = colB < a.ldJ;
@@ -66,7 +71,7 @@ __global__ __launch_bounds__(64) void k_normal_eq(const NormalEqArgs a) {
     if (n <= 0 || nd <= 0) continue;
     const float scale = sg.weight / (float)nd;
     const float* base = sg.rows + (size_t)b * sg.inst_stride + (size_t)sg.row_offset * a.ldJ;
-    // software pipeline: the 12 loads of step r0+8 are issued before the 4 MFMAs of step r0
+    // software pipeline: the 12 loads of this wave's next row group are issued before the 4 MFMAs of the current one
     auto load_step = [&](int r0, float (&av)[4], float (&bv)[4]) {
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
@@ -81,21 +86,34 @@ __global__ __launch_bounds__(64) void k_normal_eq(const NormalEqArgs a) {
       }
     };
     float av[4], bv[4], an[4], bn[4];
-    load_step(0, av, bv);
-    for (int r0 = 0; r0 < n; r0 += 8) {
-      if (r0 + 8 < n) load_step(r0 + 8, an, bn);
+    const int stride = 8 * KSPLIT;
+    load_step(8 * ws, av, bv);
+    for (int r0 = 8 * ws; r0 < n; r0 += stride) {
+      if (r0 + stride < n) load_step(r0 + stride, an, bn);
 #pragma unroll
       for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bv[t], acc, 0, 0, 0);
 #pragma unroll
       for (int t = 0; t < 4; ++t) { av[t] = an[t]; bv[t] = bn[t]; }
     }
   }
-  float* H = a.Hext + (size_t)b * a.ldJ * a.ldJ;
+  // fixed-order reduction of the KSPLIT partial accumulators (wave 0 adds waves 1, 2, 3 in that order)
+  if (ws > 0) {
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int row = bi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-    const int col = bj * 32 + c;
-    if (row < a.ldJ && col < a.ldJ) H[(size_t)row * a.ldJ + col] = acc[r];
+    for (int r = 0; r < 16; ++r) part[ws - 1][r][lane] = acc[r];
+  }
+  __syncthreads();
+  if (ws == 0) {
+#pragma unroll
+    for (int w2 = 0; w2 < KSPLIT - 1; ++w2)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] += part[w2][r][lane];
+    float* H = a.Hext + (size_t)b * a.ldJ * a.ldJ;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = bi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      const int col = bj * 32 + c;
+      if (row < a.ldJ && col < a.ldJ) H[(size_t)row * a.ldJ + col] = acc[r];
+    }
   }
 }
 
@@ -110,7 +128,7 @@ int launch_normal_eq(const RowSegment* segs, int n_seg, int L, int B, const int*
   const int npair = a.nblk * (a.nblk + 1) / 2;
   const int inst_per_xcd = (B + 7) / 8;
   const int grid = inst_per_xcd * npair * 8;
-  hipLaunchKernelGGL(k_normal_eq, dim3(grid), dim3(64), 0, stream, a);
+  hipLaunchKernelGGL(k_normal_eq, dim3(grid), dim3(64 * KSPLIT), 0, stream, a);
   HM_CHECK_HIP(hipGetLastError());
   return 0;
 }
