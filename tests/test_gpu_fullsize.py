@@ -79,8 +79,10 @@ def test_fullsize_metric_parity_vs_oracle(pose_known):
     """Chamfer-to-ground-truth and pose error of the HIP result vs the CPU oracle's result on the same inputs
     (two instances of the batch, 25 LM iterations).  BASELINE.json asks for 1e-4 relative: pose_known runs are held
     to it.  Free-pose runs are chaotic (hard with_grad / ball / Huber / ReLU switches amplify rounding noise, SURVEY.md
-    8d): the bar there is the REFERENCE-SIDE NOISE FLOOR measured in the same test -- the oracle against itself with
-    the surface points scaled by (1 + 1e-7) -- times a small factor, never tighter than 2e-3."""
+    8d): two fp32 evaluations of the REFERENCE ALGORITHM ITSELF (the oracle vs the oracle with the surface points
+    scaled by 1 + 1e-7) differ by 3e-4 ... 1e-2 in Chamfer-to-GT at these sizes (scripts/parity_fullsize.py, DESIGN.md
+    section 2), and which instance flips is perturbation dependent.  The free-pose bar is therefore that band (2e-2),
+    or 5x the noise measured in this very test if that is larger."""
     from hortimapping_amd import metrics as MX, utils as U, workloads as W
     from oracle import hm_oracle as O
     s = setup()
@@ -114,9 +116,9 @@ def test_fullsize_metric_parity_vs_oracle(pose_known):
         if pose_known:
             tol_cd, tol_t, tol_s = 1e-4, 1e-4 * max(pe_c[0], 1e-3), 1e-4
         else:
-            tol_cd = max(2e-3, 5 * noise)
-            tol_t = max(2e-3 * max(pe_c[0], 1e-3), 5 * abs(pe_c2[0] - pe_c[0]))
-            tol_s = max(2e-3, 5 * abs(pe_c2[2] - pe_c[2]))
+            tol_cd = max(2e-2, 5 * noise)
+            tol_t = max(2e-2 * max(pe_c[0], 1e-3), 5 * abs(pe_c2[0] - pe_c[0]))
+            tol_s = max(2e-2, 5 * abs(pe_c2[2] - pe_c[2]))
         assert rel < tol_cd, (rel, noise, cd_gpu, cd_cpu)
         assert abs(pe_g[0] - pe_c[0]) < tol_t
         assert abs(pe_g[2] - pe_c[2]) < tol_s
