@@ -264,6 +264,22 @@ def optimize_batch(dec: DecoderWeights, opt: dict, instances: Sequence[Instance]
     return [Result(lat[b].clone(), T[b].reshape(4, 4).clone(), int(it[b]), int(st[b])) for b in range(pb.B)]
 
 
+def optimize_grouped(jobs: Sequence[tuple], shape_only: bool = False, device="cuda") -> List[Result]:
+    """Mixed workloads (BASELINE.json configs[4]: pepper + berry decoders, different YAML blocks in one job list).
+    `jobs` is a list of (DecoderWeights, opt_dict, Instance).  Instances are grouped by (decoder, config) so that each
+    batch runs with ONE resident weight set and ONE option block; groups run back to back and the results are
+    scattered back so that result i belongs to job i (identical instance indexing)."""
+    groups = {}
+    for i, (dec, opt, inst) in enumerate(jobs):
+        groups.setdefault((id(dec), id(opt)), (dec, opt, []))[2].append((i, inst))
+    out: List[Optional[Result]] = [None] * len(jobs)
+    for dec, opt, members in groups.values():
+        res = optimize_batch(dec, opt, [m[1] for m in members], shape_only, None, device)
+        for (i, _), r in zip(members, res):
+            out[i] = r
+    return out
+
+
 class Optimizer(object):
     """Drop-in for `wild_completion.optimizer.Optimizer` (optimizer.py:16-25)."""
 

@@ -1,0 +1,135 @@
+"""GPU parity tests for the other BASELINE.json configurations (parity-test cases, not bench lines), at their real
+render-block sizes, GPU (both arithmetics) vs the CPU oracle on identical synthetic inputs:
+  configs[0]  wild_pepper.yaml semantics (Sim(3), logistic occupancy, occlusion-aware, early exits), 3 instances
+  configs[2]  shape_completion_challenge_pepper.yaml semantics (pose_known, linear occupancy, 5 x 300 x 20)
+  configs[4]  mixed pepper (lab_pepper.yaml, SE(3)) + berry (lab_berry.yaml, Sim(3)) decoders in one job list
+Decoders/data are synthetic (the reference ships no weights or data); option blocks are read from configs/*.yaml."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import yaml
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(params=["f32", "f16x3"], autouse=True, scope="module")
+def precision(request):
+    os.environ["HM_PRECISION"] = request.param
+    yield request.param
+    os.environ.pop("HM_PRECISION", None)
+
+
+def load_opt(name):
+    return yaml.safe_load(open(os.path.join(ROOT, "configs", name)))["opt"]
+
+
+def make(L, seed, r0, aniso, ids, **kw):
+    from hortimapping_amd import synthetic as S, workloads as W
+    from hortimapping_amd.decoder import DecoderWeights
+    from oracle import hm_oracle as O
+    p = S.make_synthetic_decoder(L, seed=seed, r0=r0, aniso=aniso)
+    dec = DecoderWeights.from_params(p)
+    Ws, bs = S.fold_weight_norm(p)
+    fac = W.gpu_sdf_factory(dec)
+    dicts = [S.make_instance(Ws, bs, L, i, sdf_fn_factory=fac, **kw) for i in ids]
+    return dec, O.fold_decoder(p), dicts
+
+
+_ORACLE = {}
+
+
+def oracle_run(od, opt, d, pose_known, key=None):
+    """CPU oracle result; cached across the two precision parametrisations (same inputs, same answer)."""
+    from oracle import hm_oracle as O
+    if key is not None and key in _ORACLE:
+        return _ORACLE[key]
+    rd = {k: [torch.from_numpy(a) for a in v] for k, v in d["render"].items()}
+    out = O.shape_pose_joint_opt(od, opt, torch.from_numpy(d["latent0"]), torch.from_numpy(d["T_ow0"]), rd,
+                                 torch.from_numpy(d["points_w"]), d["cube_radius"], pose_known=pose_known)
+    if key is not None:
+        _ORACLE[key] = out
+    return out
+
+
+def rel(a, b):
+    return float((a - b).abs().max() / b.abs().max())
+
+
+def test_config0_wild_pepper_three_instances():
+    """wild_pepper.yaml: n_frame 10 (4 frames available per instance), 200 fg + 200 bg rays, 30 samples, max_iter 50."""
+    from hortimapping_amd import optimizer as HO, workloads as W
+    opt = load_opt("wild_pepper.yaml")
+    dec, od, dicts = make(32, 1, 0.04, (1.0, 0.75, 1.3), [0, 1, 2], n_pts=1000, n_frames=2, n_fg=200, n_bg=200)
+    dicts[1]["points_w"] = dicts[1]["points_w"][:777]                  # ragged point counts
+    for known in (True, False):
+        res = HO.optimize_batch(dec, opt, [W.to_instance(d, pose_known=known) for d in dicts])
+        for d, r in zip(dicts, res):
+            z, T, n = oracle_run(od, opt, d, known, ("c0", d["id"], known))
+            assert r.status in (1, 2, 4, 8)
+            if known:
+                # the exit tests are thresholds on rounding-sensitive quantities (max|dc/z| < 1e-2 with z_i ~ 0):
+                # after ~45 iterations the count may differ by one or two
+                assert abs(r.iter_count - n) <= 2
+                tol = (2e-3, 1e-4) if r.iter_count == n else (5e-2, 1e-3)
+                assert rel(r.latent, z) < tol[0] and rel(r.T_ow, T) < tol[1]
+            else:        # free pose: chaotic trajectories -- same exit class, close pose
+                assert abs(r.iter_count - n) <= 10
+                assert rel(r.T_ow, T) < 5e-2
+
+
+def test_config2_challenge_semantics():
+    """shape_completion_challenge_pepper.yaml: T_ow = I-like init, pose_known=True (run_shape_completion_challenge.py:207-218)."""
+    from hortimapping_amd import optimizer as HO, workloads as W
+    opt = load_opt("shape_completion_challenge_pepper.yaml")
+    dec, od, dicts = make(32, 1, 0.04, (1.0, 0.75, 1.3), [5, 6], n_pts=1500, n_frames=5, n_fg=200, n_bg=100)
+    res = HO.optimize_batch(dec, opt, [W.to_instance(d, pose_known=True) for d in dicts])
+    for d, r in zip(dicts, res):
+        z, T, n = oracle_run(od, opt, d, True, ("c2", d["id"]))
+        assert r.iter_count == n
+        assert rel(r.latent, z) < 2e-3 and rel(r.T_ow, T) < 1e-4
+
+
+def test_config4_mixed_pepper_and_berry_grouping():
+    """lab_pepper.yaml (SE(3), linear occupancy, M = 20, r = 0.08) + lab_berry.yaml (Sim(3), logistic, M = 15,
+    r = 0.04, s_damp = 0) interleaved in one job list: grouped by decoder, results in job order."""
+    from hortimapping_amd import optimizer as HO, workloads as W
+    opt_p, opt_b = load_opt("lab_pepper.yaml"), load_opt("lab_berry.yaml")
+    for o in (opt_p, opt_b):
+        o["converge"]["max_iter"] = 8
+    dec_p, od_p, dp = make(32, 1, 0.04, (1.0, 0.75, 1.3), [0, 1], n_pts=900, n_frames=3, n_fg=200, n_bg=100)
+    dec_b, od_b, db = make(32, 3, 0.02, (1.0, 1.2, 0.9), [2, 3], n_pts=700, n_frames=3, n_fg=300, n_bg=150,
+                           r_max=0.04)
+    jobs = [(dec_p, opt_p, W.to_instance(dp[0], True)), (dec_b, opt_b, W.to_instance(db[0], True)),
+            (dec_p, opt_p, W.to_instance(dp[1], True)), (dec_b, opt_b, W.to_instance(db[1], True))]
+    res = HO.optimize_grouped(jobs)
+    refs = [(od_p, opt_p, dp[0]), (od_b, opt_b, db[0]), (od_p, opt_p, dp[1]), (od_b, opt_b, db[1])]
+    for j, (r, (od, opt, d)) in enumerate(zip(res, refs)):
+        z, T, n = oracle_run(od, opt, d, True, ("c4", j))
+        assert r.iter_count == n
+        assert rel(r.latent, z) < 2e-3 and rel(r.T_ow, T) < 1e-4
+
+
+def test_config3_many_instances_sharded_single_rank():
+    """configs[3] in miniature on one GPU: 160 instances through distributed.optimize_sharded in batches of 64;
+    results come back in instance order and equal the direct batched run bit for bit."""
+    from hortimapping_amd import distributed as D, optimizer as HO, workloads as W
+    opt = W.c2_opt_cfg(max_iter=3)
+    dec, od, dicts = make(32, 1, 0.04, (1.0, 0.75, 1.3), list(range(20)), n_pts=256, n_frames=1, n_fg=32, n_bg=32)
+    insts = [W.to_instance(dicts[i % 20]) for i in range(160)]
+    direct = HO.optimize_batch(dec, opt, insts[:64])
+
+    def run_local(lo, hi):
+        out = []
+        for s in range(lo, hi, 64):
+            out += HO.optimize_batch(dec, opt, insts[s:min(hi, s + 64)])
+        return (torch.stack([r.latent for r in out]), torch.stack([r.T_ow.reshape(16) for r in out]),
+                torch.tensor([r.iter_count for r in out], dtype=torch.int32),
+                torch.tensor([r.status for r in out], dtype=torch.int32))
+    lat, T, it, st = D.optimize_sharded(run_local, 160, 32, torch.device("cuda"))
+    assert lat.shape == (160, 32) and int(it.min()) == 3
+    for i in range(64):
+        assert torch.equal(lat[i].cpu(), direct[i].latent) and torch.equal(T[i].cpu(), direct[i].T_ow)
+    assert torch.equal(lat[:20].cpu(), lat[140:160].cpu())          # instance i and i+20k are the same fruit
