@@ -1,0 +1,218 @@
+"""Mesh extraction after the optimisation (SURVEY.md 8f "next" row 1): mirror of `wild_completion/mesher.py`.
+
+`MeshExtractor(decoder, code_len, voxels_dim, cube_radius)` keeps the reference's constructor and methods
+(`extract_mesh_from_code`, `complete_mesh`).  The voxels_dim^3 grid is decoded by the forward MFMA kernel
+(`hm_decode_batch`, batched over instances) and the zero level set is extracted on the GPU by `hm_extract_surface`
+(marching tetrahedra; scikit-image's marching cubes, used by the reference at utils.py:573-576, is not in the image).
+Open3D is not available either, so `complete_mesh` returns a small `TriangleMesh` record instead of an
+`o3d.geometry.TriangleMesh`; `write_ply` writes the binary little-endian PLY layout of `write_mesh_to_ply`
+(utils.py:591-611: vertex x,y,z float32; face vertex_indices int32 list)."""
+from __future__ import annotations
+
+import ctypes
+from dataclasses import dataclass
+from typing import List, Optional
+
+import numpy as np
+import torch
+
+from . import _lib, ops
+from .utils import as_weights
+
+
+def create_voxel_grid(vol_dim: int = 128) -> torch.Tensor:
+    """`wild_completion/utils.py:542-562`: (vol_dim^3, 3) sample positions in [-1, 1]^3, row index = (ix n + iy) n + iz.
+
+    Faithful to what the reference computes under its pinned torch (>= 1.5 semantics, README.md:39): the index
+    arithmetic `overall_index.long() / vol_dim` is a TRUE division, so only z is a lattice coordinate; the y and x
+    "indices" carry the fractional carries iz/n and (iy + iz/n)/n, i.e. the sample positions are sheared by less than
+    one voxel while the mesher still treats the decoded values as a regular grid (utils.py:573-586).  Reproduced, not
+    fixed, so that completed meshes match the reference's."""
+    n = int(vol_dim)
+    voxel_size = 2.0 / (n - 1)
+    idx = torch.arange(0, n ** 3, dtype=torch.long)
+    v = torch.zeros(n ** 3, 3)
+    v[:, 2] = idx % n
+    v[:, 1] = (idx / n) % n
+    v[:, 0] = ((idx / n) / n) % n
+    v[:, 0] = v[:, 0] * voxel_size - 1.0
+    v[:, 1] = v[:, 1] * voxel_size - 1.0
+    v[:, 2] = v[:, 2] * voxel_size - 1.0
+    return v
+
+
+@dataclass
+class TriangleMesh:
+    vertices: np.ndarray            # (V, 3) float32
+    faces: np.ndarray               # (F, 3) int32
+    color: Optional[np.ndarray] = None
+
+    def transform(self, T) -> "TriangleMesh":
+        T = np.asarray(T, dtype=np.float64)
+        v = self.vertices.astype(np.float64) @ T[:3, :3].T + T[:3, 3]
+        return TriangleMesh(v.astype(np.float32), self.faces, self.color)
+
+    def area(self) -> float:
+        a, b, c = (self.vertices[self.faces[:, k]].astype(np.float64) for k in range(3))
+        return float(0.5 * np.linalg.norm(np.cross(b - a, c - a), axis=1).sum())
+
+    def sample_points_uniformly(self, n: int, seed: int = 0) -> np.ndarray:
+        """Area-weighted uniform samples (what Metrics3D.convert_to_pcd asks Open3D for, metrics_3d/metric.py:41)."""
+        rs = np.random.RandomState(seed)
+        a, b, c = (self.vertices[self.faces[:, k]].astype(np.float64) for k in range(3))
+        w = 0.5 * np.linalg.norm(np.cross(b - a, c - a), axis=1)
+        f = rs.choice(len(w), size=n, p=w / w.sum())
+        r1, r2 = np.sqrt(rs.rand(n)), rs.rand(n)
+        return (1 - r1)[:, None] * a[f] + (r1 * (1 - r2))[:, None] * b[f] + (r1 * r2)[:, None] * c[f]
+
+
+def _declare(lib):
+    if getattr(lib, "_hm_mesh_declared", False):
+        return
+    vp, ci = ctypes.c_void_p, ctypes.c_int
+    lib.hm_extract_surface.restype = ci
+    lib.hm_extract_surface.argtypes = [ci, vp, ci, ctypes.c_float, ctypes.c_float, vp, vp, vp, ci, vp]
+    lib._hm_mesh_declared = True
+
+
+def extract_surface(sdf: torch.Tensor, cube_radius: float, level: float = 0.0, max_tris: int = 0):
+    """sdf (B, n, n, n) cuda f32 -> list of (T_b, 3, 3) float32 triangle soups (object frame)."""
+    lib = _lib.lib()
+    _declare(lib)
+    assert sdf.is_cuda and sdf.dtype == torch.float32 and sdf.dim() == 4
+    sdf = sdf.contiguous()
+    B, n = sdf.shape[0], sdf.shape[1]
+    ncell = (n - 1) ** 3
+    cap = int(max_tris) if max_tris > 0 else max(4096, 16 * n * n)
+    while True:
+        offsets = torch.empty(B, ncell, dtype=torch.int32, device=sdf.device)
+        count = torch.zeros(B, dtype=torch.int32, device=sdf.device)
+        tris = torch.empty(B, cap, 9, dtype=torch.float32, device=sdf.device)
+        rc = lib.hm_extract_surface(B, sdf.data_ptr(), n, float(level), float(cube_radius), offsets.data_ptr(),
+                                    count.data_ptr(), tris.data_ptr(), cap, torch.cuda.current_stream().cuda_stream)
+        _lib.check(rc, "hm_extract_surface")
+        cnt = count.cpu().numpy()
+        if int(cnt.max()) <= cap:
+            break
+        cap = int(cnt.max())
+    return [tris[b, :int(cnt[b])].reshape(-1, 3, 3).cpu().numpy() for b in range(B)]
+
+
+def weld(soup: np.ndarray):
+    """Triangle soup (T,3,3) -> (vertices (V,3) f32, faces (T,3) i32).  Shared edge vertices are bit-identical by
+    construction (see hm_mesh.hip), so an exact `unique` welds them."""
+    if soup.shape[0] == 0:
+        return np.zeros((0, 3), np.float32), np.zeros((0, 3), np.int32)
+    flat = np.ascontiguousarray(soup.reshape(-1, 3))
+    v, inv = np.unique(flat, axis=0, return_inverse=True)
+    f = inv.reshape(-1, 3).astype(np.int32)
+    # the level set passing exactly through a grid node collapses an edge: drop zero-area triangles
+    keep = (f[:, 0] != f[:, 1]) & (f[:, 1] != f[:, 2]) & (f[:, 0] != f[:, 2])
+    return v.astype(np.float32), np.ascontiguousarray(f[keep])
+
+
+class MeshExtractor(object):
+    """Drop-in for `wild_completion.mesher.MeshExtractor` (mesher.py:5-32)."""
+
+    def __init__(self, decoder, code_len=64, voxels_dim=64, cube_radius=1.0):
+        self.decoder = as_weights(decoder)
+        self.code_len = code_len
+        self.voxels_dim = int(voxels_dim)
+        self.cube_radius = float(cube_radius)
+        self.voxel_points = create_voxel_grid(self.voxels_dim) * self.cube_radius        # mesher.py:11-12
+        n3 = self.voxels_dim ** 3
+        self._npad = (n3 + 63) // 64 * 64
+        pts4 = torch.zeros(self._npad, 4)
+        pts4[:n3, :3] = self.voxel_points
+        self._pts4 = pts4.cuda()
+
+    def decode_grids(self, latents: torch.Tensor) -> torch.Tensor:
+        """(B, L) latents -> (B, n, n, n) sdf grids, all instances in one forward launch."""
+        lat = latents.detach().to("cuda", torch.float32).reshape(-1, self.decoder.latent_dim).contiguous()
+        B = lat.shape[0]
+        n3 = self.voxels_dim ** 3
+        pts = self._pts4[None].expand(B, -1, -1).contiguous()
+        nq = torch.full((B,), n3, dtype=torch.int32, device="cuda")
+        y, _ = ops.decode_batch(self.decoder, lat, pts, nq, mode=0)
+        n = self.voxels_dim
+        return y[:, :n3].reshape(B, n, n, n)
+
+    def extract_meshes(self, latents: torch.Tensor) -> List[TriangleMesh]:
+        soups = extract_surface(self.decode_grids(latents), self.cube_radius)
+        return [TriangleMesh(*weld(s)) for s in soups]
+
+    def extract_mesh_from_code(self, code):
+        """mesher.py:14-24 -> dict with `vertices` (float32) and `faces` (int32)."""
+        m = self.extract_meshes(code.reshape(1, -1))[0]
+        return {"vertices": m.vertices, "faces": m.faces}
+
+    def complete_mesh(self, latent, transform, color=None) -> TriangleMesh:
+        """mesher.py:26-32: mesh of the code, painted and moved by `transform` (object -> world)."""
+        m = self.extract_meshes(latent.reshape(1, -1))[0]
+        m.color = None if color is None else np.asarray(color, dtype=np.float32)
+        return m.transform(transform)
+
+
+def write_ply(mesh: TriangleMesh, path: str):
+    """Binary little-endian PLY with the element layout of `write_mesh_to_ply` (utils.py:591-611)."""
+    v = np.ascontiguousarray(mesh.vertices, dtype="<f4")
+    f = np.ascontiguousarray(mesh.faces, dtype="<i4")
+    header = ("ply\nformat binary_little_endian 1.0\n"
+              f"element vertex {v.shape[0]}\nproperty float x\nproperty float y\nproperty float z\n"
+              f"element face {f.shape[0]}\nproperty list uchar int vertex_indices\nend_header\n")
+    rec = np.zeros(f.shape[0], dtype=[("n", "u1"), ("idx", "<i4", (3,))])
+    rec["n"] = 3
+    rec["idx"] = f
+    with open(path, "wb") as fh:
+        fh.write(header.encode("ascii"))
+        fh.write(v.tobytes())
+        fh.write(rec.tobytes())
+
+
+def read_ply(path: str) -> TriangleMesh:
+    """Minimal PLY reader (ascii or binary little-endian; vertex x,y,z [+ extra float/uchar props], triangle faces)."""
+    with open(path, "rb") as fh:
+        data = fh.read()
+    end = data.index(b"end_header\n") + len(b"end_header\n")
+    lines = data[:end].decode("ascii", "replace").split("\n")
+    fmt = [l.split()[1] for l in lines if l.startswith("format")][0]
+    elems, cur = [], None
+    for l in lines:
+        t = l.split()
+        if not t:
+            continue
+        if t[0] == "element":
+            cur = {"name": t[1], "count": int(t[2]), "props": []}
+            elems.append(cur)
+        elif t[0] == "property" and cur is not None:
+            cur["props"].append(t[1:])
+    np_t = {"float": "<f4", "float32": "<f4", "double": "<f8", "float64": "<f8", "uchar": "u1", "uint8": "u1",
+            "char": "i1", "int": "<i4", "int32": "<i4", "uint": "<u4", "short": "<i2", "ushort": "<u2"}
+    verts, faces = None, np.zeros((0, 3), np.int32)
+    if fmt == "ascii":
+        body = data[end:].decode("ascii").split("\n")
+        pos = 0
+        for e in elems:
+            rows = [body[pos + i].split() for i in range(e["count"])]
+            pos += e["count"]
+            if e["name"] == "vertex":
+                names = [p[-1] for p in e["props"]]
+                arr = np.array(rows, dtype=np.float64)
+                verts = arr[:, [names.index("x"), names.index("y"), names.index("z")]].astype(np.float32)
+            elif e["name"] == "face" and e["count"]:
+                faces = np.array([[int(r[1]), int(r[2]), int(r[3])] for r in rows], dtype=np.int32)
+    else:
+        off = end
+        for e in elems:
+            if e["name"] == "vertex":
+                dt = np.dtype([(p[-1], np_t[p[0]]) for p in e["props"]])
+                arr = np.frombuffer(data, dtype=dt, count=e["count"], offset=off)
+                off += dt.itemsize * e["count"]
+                verts = np.stack([arr["x"], arr["y"], arr["z"]], axis=1).astype(np.float32)
+            elif e["name"] == "face":
+                p = e["props"][0]          # list <count type> <index type> vertex_indices
+                dt = np.dtype([("n", np_t[p[1]]), ("idx", np_t[p[2]], (3,))])
+                arr = np.frombuffer(data, dtype=dt, count=e["count"], offset=off)
+                off += dt.itemsize * e["count"]
+                faces = arr["idx"].astype(np.int32)
+    return TriangleMesh(verts, faces)

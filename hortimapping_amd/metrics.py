@@ -59,3 +59,82 @@ def pose_error(T_ow: np.ndarray, T_wo_true: np.ndarray):
     c = (np.trace(R @ Rt.T) - 1) / 2
     return (float(np.linalg.norm(T_wo[:3, 3] - Tt[:3, 3])), float(np.degrees(np.arccos(np.clip(c, -1, 1)))),
             float(s / st))
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Mirrors of the reference's evaluation classes (`metrics_3d/chamfer_distance.py`, `metrics_3d/precision_recall.py`),
+# SURVEY.md 8f "next" row 3.  Geometry arguments are (N,3) arrays / tensors or `mesher.TriangleMesh` (sampled with
+# 1,000,000 points like Metrics3D.convert_to_pcd, metrics_3d/metric.py:35-55); nearest neighbours by scipy's cKDTree
+# (the reference uses Open3D's compute_point_cloud_distance: same unsquared Euclidean NN distance).
+# ------------------------------------------------------------------------------------------------------------------
+def _to_points(geom, n_mesh_samples=1000000) -> np.ndarray:
+    if hasattr(geom, "sample_points_uniformly"):
+        return geom.sample_points_uniformly(n_mesh_samples)
+    if isinstance(geom, torch.Tensor):
+        geom = geom.detach().cpu().numpy()
+    return np.asarray(geom, dtype=np.float64)[:, :3]
+
+
+def _nn(a: np.ndarray, b: np.ndarray) -> np.ndarray:
+    from scipy.spatial import cKDTree
+    return cKDTree(b).query(a)[0]
+
+
+class ChamferDistance:
+    """metrics_3d/chamfer_distance.py:11-37."""
+
+    def __init__(self, n_mesh_samples=1000000):
+        self.cd_array = []
+        self.n_mesh_samples = n_mesh_samples
+
+    def update(self, gt, pt):
+        p = _to_points(pt, self.n_mesh_samples)
+        if len(p) == 0:
+            self.cd_array.append(0)                      # :17-19
+            return
+        g = _to_points(gt, self.n_mesh_samples)
+        self.cd_array.append((np.mean(_nn(g, p)) + np.mean(_nn(p, g))) / 2)     # :23-25
+
+    def reset(self):
+        self.cd_array = []
+
+    def compute(self):
+        return sum(self.cd_array) / len(self.cd_array)
+
+
+class PrecisionRecall:
+    """metrics_3d/precision_recall.py:11-98: precision / recall / F-score [%] over a linspace of thresholds."""
+
+    def __init__(self, min_t, max_t, num, n_mesh_samples=1000000):
+        self.thresholds = np.linspace(min_t, max_t, num)
+        self.n_mesh_samples = n_mesh_samples
+        self.reset()
+
+    def reset(self):
+        self.pr_dict = {t: [] for t in self.thresholds}
+        self.re_dict = {t: [] for t in self.thresholds}
+        self.f1_dict = {t: [] for t in self.thresholds}
+
+    def update(self, gt, pt):
+        p = _to_points(pt, self.n_mesh_samples)
+        if len(p) == 0:                                   # :20-25
+            for t in self.thresholds:
+                self.pr_dict[t].append(0); self.re_dict[t].append(0); self.f1_dict[t].append(0)
+            return
+        g = _to_points(gt, self.n_mesh_samples)
+        d_pg, d_gp = _nn(p, g), _nn(g, p)                 # precision: predicted -> gt; recall: gt -> predicted
+        for t in self.thresholds:
+            pr = 100 / len(d_pg) * int((d_pg < t).sum())
+            re = 100 / len(d_gp) * int((d_gp < t).sum())
+            f = 0 if (pr == 0 or re == 0) else 2 * pr * re / (pr + re)
+            self.pr_dict[t].append(pr); self.re_dict[t].append(re); self.f1_dict[t].append(f)
+
+    def find_nearest_threshold(self, value):
+        return self.thresholds[(np.abs(self.thresholds - value)).argmin()]
+
+    def compute_at_threshold(self, threshold):
+        t = self.find_nearest_threshold(threshold)
+        pr = sum(self.pr_dict[t]) / len(self.pr_dict[t])
+        re = sum(self.re_dict[t]) / len(self.re_dict[t])
+        f1 = sum(self.f1_dict[t]) / len(self.f1_dict[t])
+        return pr, re, f1, t

@@ -160,6 +160,14 @@ int hm_render_residuals(hm_workspace_t ws, const hm_opt_cfg* cfg, const hm_batch
                         const float* d_frame_override, float* d_rows, int* d_V, int* d_ray_row, int* d_counts,
                         void* stream);
 
+/* ---- next row: iso-surface of a decoded SDF grid; replaces convert_sdf_voxels_to_mesh
+ * (wild_completion/utils.py:565-588, scikit-image marching cubes on the host) by marching tetrahedra on the GPU over the
+ * same grid.  d_sdf [B][n^3] with index (ix*n + iy)*n + iz (the layout create_voxel_grid produces, utils.py:542-562);
+ * d_offsets: scratch of B*(n-1)^3 ints; d_tri_count [B]: triangles found (may exceed max_tris: then only cells that fit
+ * were emitted); d_tris [B][max_tris][9]: xyz of the three vertices, object frame, grid [-1,1]^3 scaled by cube_radius. */
+int hm_extract_surface(int B, const float* d_sdf, int n, float level, float cube_radius, int* d_offsets,
+                       int* d_tri_count, float* d_tris, int max_tris, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -340,6 +340,9 @@ def main():
         out[f"pix_bg_{f}"] = rdat["pix_bg"][f]
     save("g10_data_prep", **out)
 
+    # ---------------- G11: create_voxel_grid (utils.py:542-562; pure torch) ----------------
+    save("g11_voxel_grid", n5=ns.utils.create_voxel_grid(5).numpy(), n8=ns.utils.create_voxel_grid(8).numpy())
+
 
 if __name__ == "__main__":
     main()

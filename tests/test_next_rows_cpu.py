@@ -1,0 +1,86 @@
+"""CPU tests of the "next" rows around the hot path: voxel grid, data prep, metrics, PLY I/O."""
+import numpy as np
+import pytest
+import torch
+
+from tests.golden_util import load
+
+
+def test_create_voxel_grid_matches_golden():
+    """G11: create_voxel_grid (utils.py:542-562)."""
+    from hortimapping_amd.mesher import create_voxel_grid
+    g = load("g11_voxel_grid")
+    assert np.allclose(create_voxel_grid(5).numpy(), g["n5"], atol=1e-7)
+    assert np.allclose(create_voxel_grid(8).numpy(), g["n8"], atol=1e-7)
+
+
+def test_get_render_data_matches_golden():
+    """G10: get_render_data (utils.py:39-109) incl. the np.random.choice pixel sub-sampling under seed 42."""
+    from hortimapping_amd.data_prep import get_render_data
+    g = load("g10_data_prep")
+    cfg = {"opt": {"render": {"n_fg_pix": int(g["n_fg_pix"]), "n_bg_pix": int(g["n_bg_pix"]), "n_bg_pad": int(g["n_bg_pad"])}}}
+    idimg, depth = g["id_img"], g["depth_img"]
+    np.random.seed(42)
+    rd = get_render_data(5, {0: idimg, 3: idimg.T.copy()}, {0: depth, 3: depth.T.copy()}, {0: np.eye(4), 3: np.eye(4)},
+                         (64, 64), np.linalg.inv(g["K64"]), cfg, min_pix_count_match=100, max_bbx_size=300)
+    assert rd["count"] == int(g["count"]) and rd["count"] >= 1
+    for f in range(rd["count"]):
+        for k in ("rays_fg", "rays_bg", "depth_fg", "depth_bg", "T_wc"):
+            assert np.array_equal(rd[k][f].numpy(), g[f"{k}_{f}"]), (k, f)
+        assert np.array_equal(rd["pix_fg"][f], g[f"pix_fg_{f}"]) and np.array_equal(rd["pix_bg"][f], g[f"pix_bg_{f}"])
+
+
+def test_metric_classes_follow_reference_definitions():
+    from hortimapping_amd.metrics import ChamferDistance, PrecisionRecall
+    A = np.array([[0.0, 0, 0], [0.004, 0, 0], [0.02, 0, 0]])
+    Bp = np.array([[0.0, 0, 0.001], [0.02, 0.003, 0]])
+    cd = ChamferDistance()
+    cd.update(A, Bp)
+    d_ab = np.array([0.001, np.sqrt(0.004 ** 2 + 0.001 ** 2), 0.003])
+    d_ba = np.array([0.001, 0.003])
+    assert abs(cd.compute() - 0.5 * (d_ab.mean() + d_ba.mean())) < 1e-12     # chamfer_distance.py:23-25 (gt=A, pt=B)
+    pr = PrecisionRecall(0.001, 0.01, 100)
+    pr.update(A, Bp)
+    p, r, f, t = pr.compute_at_threshold(0.005)
+    assert abs(t - 0.005) < 1e-4
+    assert p == 100.0 and abs(r - 100.0) < 1e-9 and abs(f - 100.0) < 1e-9
+    p, r, f, t = pr.compute_at_threshold(0.002)
+    assert abs(p - 50.0) < 1e-9 and abs(r - 100 / 3) < 1e-9                   # precision: pred -> gt, recall: gt -> pred
+    cd.update(A, np.zeros((0, 3)))                                             # empty prediction counts as 0 (:17-19)
+    assert cd.cd_array[-1] == 0
+
+
+def test_ply_roundtrip_and_mesh_helpers(tmp_path):
+    from hortimapping_amd.mesher import TriangleMesh, read_ply, weld, write_ply
+    soup = np.array([[[0, 0, 0], [1, 0, 0], [0, 1, 0]], [[1, 0, 0], [1, 1, 0], [0, 1, 0]]], dtype=np.float32)
+    v, f = weld(soup)
+    assert v.shape == (4, 3) and f.shape == (2, 3)
+    m = TriangleMesh(v, f)
+    assert abs(m.area() - 1.0) < 1e-6
+    p = str(tmp_path / "m.ply")
+    write_ply(m, p)
+    m2 = read_ply(p)
+    assert np.array_equal(m2.vertices, v) and np.array_equal(m2.faces, f)
+    T = np.eye(4); T[:3, :3] *= 2; T[:3, 3] = [1, 2, 3]
+    assert abs(m.transform(T).area() - 4.0) < 1e-5
+    pts = m.sample_points_uniformly(1000)
+    assert pts.shape == (1000, 3) and pts.min() >= 0 and pts.max() <= 1 and np.allclose(pts[:, 2], 0)
+
+
+def test_pose_init_and_cleaning():
+    from hortimapping_amd.data_prep import clean_pcd, get_pose_init, init_T_wo
+    rs = np.random.RandomState(0)
+    d = rs.randn(12000, 3); d /= np.linalg.norm(d, axis=1, keepdims=True)
+    d = d[d[:, 2] < -0.3][:2000]                                              # camera-facing cap, like a real submap
+    fruit = np.array([0.1, 0.2, 0.5]) + 0.04 * d
+    noise = np.array([0.3, 0.3, 0.8]) + 0.002 * rs.randn(30, 3)               # an isolated small cluster
+    clean = clean_pcd(np.concatenate([fruit, noise]), 0.01, 0.02)
+    assert clean.shape[0] == 2000
+    bg = np.array([0.1, 0.2 + 0.05, 0.5 + 0.06]) + 0.005 * rs.randn(200, 3)    # peduncle support behind/above
+    c, rot, size, ok = get_pose_init(clean, bg)
+    assert ok and 0.07 < size < 0.095 and abs(c[0] - 0.1) < 2e-3 and -0.8 < rot < 0.8
+    opt = {"pose_init": {"rot_on": True, "scale_on": True}}
+    T = init_T_wo(c, rot, size, opt, 0.08)
+    assert abs(np.cbrt(np.linalg.det(T[:3, :3])) - max(size / (2 * 0.064), 0.5)) < 1e-9
+    _, _, _, ok2 = get_pose_init(fruit * 10, bg)                                # 0.8 m object: rejected (utils.py:431-433)
+    assert not ok2
