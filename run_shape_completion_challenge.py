@@ -1,0 +1,104 @@
+#!/usr/bin/env python3
+"""Entry point #2 of the reference, kept as the drop-in surface:  python run_shape_completion_challenge.py [-c <yaml>]
+
+Same option / YAML schema / dataset layout / result files / printed metrics as the reference's
+`run_shape_completion_challenge.py:36-277` (masked RGB-D -> completed fruit; Chamfer distance, precision / recall /
+F-score at 5 mm, timing, iterations), with all fruits of the split optimised in one batched call
+(`pose_known=True`, T_ow = identity, :207-218).  `baseline_name: DeepSDF` selects the shape-only optimiser (:215-216).
+"""
+import os
+import time
+
+import click
+import numpy as np
+import torch
+import yaml
+from numpy.linalg import inv
+
+from hortimapping_amd import data_prep as DP, datasets as DS
+from hortimapping_amd.mesher import MeshExtractor, write_ply
+from hortimapping_amd.metrics import ChamferDistance, PrecisionRecall
+from hortimapping_amd.optimizer import Instance, Optimizer
+from test_wild_completion import load_decoder
+
+
+@click.command()
+@click.option("--config", "-c", type=str, help="path to the config file (.yaml)",
+              default=os.path.join(os.path.dirname(os.path.abspath(__file__)),
+                                   "configs/shape_completion_challenge_pepper.yaml"))
+def main(config):
+    np.random.seed(42)
+    torch.manual_seed(42)
+    cfg = yaml.safe_load(open(config))
+    dtype = torch.float32
+    decoder, init_latent, _ = load_decoder(cfg)
+    code_len = init_latent.shape[0]
+    object_radius_max_m = float(cfg["vis"]["object_radius_max_m"])
+    voxels_dim = int(2 * object_radius_max_m * 1e3 / float(cfg["vis"]["mc_res_mm"]))
+    deepsdf_baseline = cfg["baseline_name"] == "DeepSDF"
+    mesh_extractor = MeshExtractor(decoder, code_len=code_len, voxels_dim=voxels_dim, cube_radius=object_radius_max_m)
+    opt = Optimizer(cfg, decoder, mesh_extractor, None)
+    cd_metric = ChamferDistance()
+    pr_metric = PrecisionRecall(min_t=0.001, max_t=0.01, num=100)          # :83
+    data = DS.ShapeCompletionDataset(cfg["data_dir"], cfg["split"])
+    result_folder = os.path.join(cfg["data_dir"], "results", cfg["run_name"], cfg["split"])
+    os.makedirs(result_folder, exist_ok=True)
+    gt_valid = cfg["split"] != "test"
+
+    jobs = []
+    for item in data:                                                       # :93
+        fid = item["fid"]
+        if "lab" in fid and cfg["skip_lab_data"]:                           # :99-104
+            continue
+        invK = inv(item["rgbd_intrinsic"])
+        frames = item["rgbd_frames"]
+        frame_ids = np.array(list(frames.keys()))
+        sel = np.linspace(0, len(frame_ids) - 1, min(len(frame_ids), cfg["frame_per_fruit"])).astype(np.int32)
+        img_size = frames[frame_ids[0]]["rgb"].shape[:-1]
+        pts = item["rgbd_pcd"]
+        r = object_radius_max_m * 1.5                                       # crop, :136-139
+        pts = pts[np.all(np.abs(pts) <= r, axis=1)]
+        n_down = cfg["opt"]["recon"]["n_pts"]
+        if pts.shape[0] > n_down:                                           # random_down_sample, :145
+            pts = pts[np.random.choice(pts.shape[0], n_down, replace=False)]
+        pts = DP.clean_pcd(pts, cfg["opt"]["recon"]["cluster_dist_m"])
+        id_imgs, depth_imgs, poses = {}, {}, {}
+        for k in frame_ids[sel]:
+            fr = frames[k]
+            id_imgs[fr["fname"]] = (fr["mask"] > 0).astype(np.int32)        # 0 or 1, cur_submap_id = 1 (:86,166)
+            depth_imgs[fr["fname"]] = fr["depth"]
+            poses[fr["fname"]] = fr["pose"]
+        render_data = DP.get_render_data(1, id_imgs, depth_imgs, poses, img_size, invK, cfg, max_bbx_size=1000)
+        inst = Instance(init_latent.clone(), torch.eye(4, dtype=dtype), torch.tensor(pts, dtype=dtype), render_data,
+                        object_radius_max_m, True)
+        jobs.append((fid, item.get("groundtruth_pcd"), inst))
+
+    t0 = time.time()
+    results = opt.optimize_batch([j[2] for j in jobs], shape_only=deepsdf_baseline) if jobs else []
+    torch.cuda.synchronize()
+    t_total = time.time() - t0
+    iters = []
+    for (fid, gt, _), res in zip(jobs, results):
+        T_wo = inv(res.T_ow.numpy().astype(np.float64))
+        mesh = mesh_extractor.complete_mesh(res.latent, T_wo, None)
+        write_ply(mesh, os.path.join(result_folder, fid + ".ply"))           # :229-230
+        iters.append(res.iter_count)
+        if gt_valid and mesh.faces.shape[0] > 0:
+            complete = mesh.sample_points_uniformly(len(gt), seed=42)        # :239
+            cd_metric.update(gt, complete)
+            pr_metric.update(gt, complete)
+    if gt_valid and jobs:
+        pr, re, f1, thre = pr_metric.compute_at_threshold(0.005)
+        print("Results on the", cfg["split"], "set")                        # :262-270
+        print("CD        [mm]:", cd_metric.compute() * 1e3)
+        print("F-score    [%]:", f1)
+        print("Precision  [%]:", pr)
+        print("Recall:    [%]:", re)
+        print("threshold [mm]:", thre)
+        print("timing     [s]:", t_total / len(jobs), "(per fruit; %d fruits optimised in one batch in %.3f s)" % (len(jobs), t_total))
+        print("iteration     :", float(np.mean(iters)))
+        print("calculated over %i frames" % len(jobs))
+
+
+if __name__ == "__main__":
+    main()

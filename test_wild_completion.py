@@ -1,0 +1,120 @@
+#!/usr/bin/env python3
+"""Entry point #1 of the reference, kept as the drop-in surface:  python test_wild_completion.py -c <yaml>
+
+Same option, same YAML schema, same input layout and same output files as the reference's
+`test_wild_completion.py:23-264` (BUP20 "wild" sequences: per-submap completion + pose files), but ALL fruit instances
+of the sequence are optimised in one batched call on the MI355X (`Optimizer.optimize_batch`) instead of one after the
+other.  Skipping rules are the reference's, applied before batching, so results stay keyed by submap file name:
+Background submap, ids below `begin_submap`, submaps without a matched frame (`get_render_data`), invalid pose
+initialisation, and the post-hoc outlier rejection on scale / pitch / roll.
+
+`deepsdf_dir` may be a DeepSDF experiment directory (specs.json + ModelParameters + LatentCodes, as in the reference)
+or `synthetic:latent=<L>,seed=<s>[,r0=<r>]` for the analytic decoder (the reference tree ships no weights)."""
+import os
+
+import click
+import numpy as np
+import torch
+import yaml
+from numpy.linalg import det, inv
+
+from hortimapping_amd import data_prep as DP, datasets as DS, synthetic as S
+from hortimapping_amd.decoder import DecoderWeights, config_decoder, load_latent_vectors
+from hortimapping_amd.mesher import MeshExtractor, read_ply, write_ply
+from hortimapping_amd.optimizer import Instance, Optimizer, STATUS_INVALID
+
+
+def load_decoder(cfg):
+    d = cfg["deepsdf_dir"]
+    if isinstance(d, str) and d.startswith("synthetic:"):
+        kv = dict(x.split("=") for x in d[len("synthetic:"):].split(","))
+        L = int(kv.get("latent", 32))
+        params = S.make_synthetic_decoder(L, seed=int(kv.get("seed", 1)), r0=float(kv.get("r0", 0.04)),
+                                          aniso=(1.0, 0.75, 1.3))
+        return DecoderWeights.from_params(params), torch.zeros(L), params
+    decoder = config_decoder(d, "latest")                               # test_wild_completion.py:44-45
+    init_latent = torch.mean(load_latent_vectors(d, "latest"), 0)       # :46-47
+    return decoder, init_latent, None
+
+
+@click.command()
+@click.option("--config", "-c", type=str, help="path to the config file (.yaml)",
+              default=os.path.join(os.path.dirname(os.path.abspath(__file__)), "configs/wild_pepper.yaml"))
+def main(config):
+    np.random.seed(42)                                                  # set_random_seed(42), utils.py:638-641
+    torch.manual_seed(42)
+    cfg = yaml.safe_load(open(config))
+    dtype = torch.float32
+    decoder, init_latent, _ = load_decoder(cfg)
+    code_len = init_latent.shape[0]
+    print("DeepSDF model loaded")
+
+    data_base = cfg["data_dir"]
+    submap_folder = os.path.join(data_base, "submaps")
+    complete_submap_folder, clean_submap_folder, pose_folder = (submap_folder + s for s in ("_complete", "_clean", "_pose"))
+    for d in (complete_submap_folder, clean_submap_folder, pose_folder):
+        os.makedirs(d, exist_ok=True)
+
+    object_radius_max_m = float(cfg["vis"]["object_radius_max_m"])
+    voxels_dim = int(2 * object_radius_max_m * 1e3 / float(cfg["vis"]["mc_res_mm"]))
+    K, _, img_size = DS.load_cam_info(cfg["cam_info_path"])
+    invK = inv(K)
+    frames = DS.load_bup20_frames(cfg)
+    print("Loaded %d frames, image size %s" % (len(frames["id"]), img_size))
+
+    mesh_extractor = MeshExtractor(decoder, code_len=code_len, voxels_dim=voxels_dim, cube_radius=object_radius_max_m)
+    opt = Optimizer(cfg, decoder, mesh_extractor, None)
+
+    jobs, bg_points = [], np.zeros((0, 3))
+    for submap_name in sorted(os.listdir(submap_folder)):                # instance loop, :133
+        submap_cat = (submap_name.split("_")[1]).split(".")[0]
+        submap_id = int(submap_name.split("_")[0])
+        if submap_id > 1 and submap_id < cfg["begin_submap"]:
+            continue
+        cur_mesh = read_ply(os.path.join(submap_folder, submap_name))
+        if submap_cat == "Background":                                   # :148-151
+            bg_points = cur_mesh.sample_points_uniformly(100000, seed=42)
+            continue
+        render_data = DP.get_render_data(submap_id, frames["id"], frames["depth"], frames["pose"], img_size, invK, cfg)
+        if render_data["count"] == 0:
+            print("Submap %d: no valid match, skip" % submap_id)
+            continue
+        pts = DP.clean_mesh(cur_mesh, cfg["opt"]["recon"]["n_pts"], cfg["opt"]["recon"]["cluster_dist_m"], seed=42)
+        center, rot_y, bbx_size, valid = DP.get_pose_init(pts, bg_points)
+        if not valid:
+            print("Submap %d: invalid pose initialisation, skip" % submap_id)
+            continue
+        T_wo = DP.init_T_wo(center, rot_y, bbx_size, cfg["opt"], object_radius_max_m)
+        inst = Instance(init_latent.clone(), torch.tensor(inv(T_wo), dtype=dtype), torch.tensor(pts, dtype=dtype),
+                        render_data, object_radius_max_m, False)
+        jobs.append((submap_name, submap_id, pts, inst))
+    print("Optimising %d fruit instances in one batch" % len(jobs))
+    results = opt.optimize_batch([j[3] for j in jobs]) if jobs else []
+
+    kept = 0
+    for (submap_name, submap_id, pts, _), res in zip(jobs, results):
+        if res.status & STATUS_INVALID:
+            print("Submap %d: not valid (no depth residuals)" % submap_id)
+        T_wo = inv(res.T_ow.numpy().astype(np.float64))
+        final_scale = det(T_wo[:3, :3]) ** (1 / 3)
+        from scipy.spatial.transform import Rotation
+        yaw, pitch, roll = Rotation.from_matrix(T_wo[:3, :3] / final_scale).as_euler("zyx", degrees=True)
+        out = cfg["opt"]["outlier"]
+        if final_scale < out["scale_min"] or final_scale > out["scale_max"]:      # :238-246
+            print("Submap %d: final scale %f is an outlier, not valid" % (submap_id, final_scale))
+            continue
+        if abs(pitch) > out["rot_max_deg"] or abs(roll) > out["rot_max_deg"]:
+            print("Submap %d: final rotation (pitch %f, roll %f) is an outlier, not valid" % (submap_id, pitch, roll))
+            continue
+        mesh = mesh_extractor.complete_mesh(res.latent, T_wo, None)
+        write_ply(mesh, os.path.join(complete_submap_folder, submap_name))       # :249-252
+        DS.write_points_ply(pts, os.path.join(clean_submap_folder, submap_name))  # :254-256
+        np.save(os.path.join(pose_folder, submap_name.replace("ply", "npy")), T_wo)   # :258-260
+        kept += 1
+        print("Submap %d: %d iterations, scale %.3f -> %s" % (submap_id, res.iter_count, final_scale,
+                                                              os.path.join(complete_submap_folder, submap_name)))
+    print("Completed %d of %d submaps" % (kept, len(jobs)))
+
+
+if __name__ == "__main__":
+    main()
