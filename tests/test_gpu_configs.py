@@ -63,10 +63,11 @@ def test_config0_wild_pepper_three_instances():
     from hortimapping_amd import optimizer as HO, workloads as W
     opt = load_opt("wild_pepper.yaml")
     dec, od, dicts = make(32, 1, 0.04, (1.0, 0.75, 1.3), [0, 1, 2], n_pts=1000, n_frames=2, n_fg=200, n_bg=200)
+    cases = [(True, [0, 1, 2]), (False, [1])]          # oracle runs are the slow part: free pose on one instance only
     dicts[1]["points_w"] = dicts[1]["points_w"][:777]                  # ragged point counts
-    for known in (True, False):
+    for known, which in cases:
         res = HO.optimize_batch(dec, opt, [W.to_instance(d, pose_known=known) for d in dicts])
-        for d, r in zip(dicts, res):
+        for d, r in [(dicts[i], res[i]) for i in which]:
             z, T, n = oracle_run(od, opt, d, known, ("c0", d["id"], known))
             assert r.status in (1, 2, 4, 8)
             if known:

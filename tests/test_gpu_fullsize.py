@@ -9,6 +9,7 @@ pytestmark = pytest.mark.gpu
 
 L, B = 256, 64
 _S = {}
+_ORACLE = {}      # CPU oracle results, shared by the two precision parametrisations
 
 
 @pytest.fixture(params=["f32", "f16x3"], autouse=True, scope="module")
@@ -77,7 +78,7 @@ def test_fullsize_frozen_after_exit():
 @pytest.mark.parametrize("pose_known", [True, False])
 def test_fullsize_metric_parity_vs_oracle(pose_known):
     """Chamfer-to-ground-truth and pose error of the HIP result vs the CPU oracle's result on the same inputs
-    (two instances of the batch, 25 LM iterations).  BASELINE.json asks for 1e-4 relative: pose_known runs are held
+    (two instances of the batch, 20 LM iterations).  BASELINE.json asks for 1e-4 relative: pose_known runs are held
     to it.  Free-pose runs are chaotic (hard with_grad / ball / Huber / ReLU switches amplify rounding noise, SURVEY.md
     8d): two fp32 evaluations of the REFERENCE ALGORITHM ITSELF (the oracle vs the oracle with the surface points
     scaled by 1 + 1e-7) differ by 3e-4 ... 1e-2 in Chamfer-to-GT at these sizes (scripts/parity_fullsize.py, DESIGN.md
@@ -86,7 +87,7 @@ def test_fullsize_metric_parity_vs_oracle(pose_known):
     from hortimapping_amd import metrics as MX, utils as U, workloads as W
     from oracle import hm_oracle as O
     s = setup()
-    n_it = 25
+    n_it = 20
     cfg = W.c2_opt_cfg(max_iter=n_it)
     pick = [3, 41]
     insts = [W.to_instance(s["dicts"][i], pose_known=pose_known) for i in range(B)]
@@ -101,9 +102,12 @@ def test_fullsize_metric_parity_vs_oracle(pose_known):
         d = s["dicts"][i]
         rd = {k: [torch.from_numpy(a) for a in v] for k, v in d["render"].items()}
         args = (od, cfg, torch.from_numpy(d["latent0"]), torch.from_numpy(d["T_ow0"]), rd)
-        z, T, n = O.shape_pose_joint_opt(*args, torch.from_numpy(d["points_w"]), d["cube_radius"], pose_known=pose_known)
-        z2, T2, _ = O.shape_pose_joint_opt(*args, torch.from_numpy(d["points_w"]) * (1 + 1e-7), d["cube_radius"],
-                                           pose_known=pose_known)
+        if (i, pose_known) not in _ORACLE:
+            a = O.shape_pose_joint_opt(*args, torch.from_numpy(d["points_w"]), d["cube_radius"], pose_known=pose_known)
+            b2 = O.shape_pose_joint_opt(*args, torch.from_numpy(d["points_w"]) * (1 + 1e-7), d["cube_radius"],
+                                        pose_known=pose_known)
+            _ORACLE[(i, pose_known)] = (a, b2)
+        (z, T, n), (z2, T2, _) = _ORACLE[(i, pose_known)]
         assert res[i].iter_count == n == n_it
         gt = pts(torch.from_numpy(d["z_true"]), torch.from_numpy(np.linalg.inv(d["T_wo_true"]).astype(np.float32)))
         cd_gpu = MX.chamfer_distance(pts(res[i].latent, res[i].T_ow), gt)
