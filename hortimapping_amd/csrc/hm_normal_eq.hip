@@ -7,8 +7,6 @@
 // The row weight is c_i = weight * rho_i / count with rho_i the squared Huber weight of r_i
 // (wild_completion/utils.py:327-358) when the robust kernel is on for that term, else 1.
 //
-// One 4-wave workgroup owns one lower-triangular 32x32 block pair of one instance; the waves split the rows of up
-// to three row segments round-robin in groups of 8 and their partial blocks are summed in a fixed order through LDS.
 // Row segments: (SDF rows, depth-render rows, mask-render rows); the blockIdx -> (instance, pair) map keeps all
 // pairs of an instance on one XCD so that the instance's rows are fetched from HBM once and re-read from that
 // XCD's L2.  Fixed summation order => bitwise reproducible.
@@ -35,30 +33,40 @@ __device__ __forceinline__ float huber_rho(float r, float th) {
   return (2.f * th * a - th * th) / (a * a);
 }
 
-constexpr int KSPLIT = 4;   // waves per block pair: each takes every 4th group of 8 rows, partials reduced through LDS
+constexpr int CH = 64;        // rows staged per chunk
+constexpr int TW = 64;        // tile width: 2 x 2 blocks of 32 columns per workgroup (one block per wave)
 
-__global__ __launch_bounds__(64 * KSPLIT) void k_normal_eq(const NormalEqArgs a) {
-  __shared__ float part[KSPLIT - 1][16][64];
-  // XCD-aware decomposition: blockIdx % 8 selects the XCD (observed dispatch rule); all pairs of an instance share it
-  const int npair = a.nblk * (a.nblk + 1) / 2;
+// One workgroup (4 waves) owns a 64 x 64 tile = 2 x 2 lower-triangular 32x32 blocks of one instance's H and walks
+// all rows of up to three row segments in chunks of 64 rows: the chunk's two 64-column strips (A side, B side) and the
+// per-row weights are staged in LDS by coalesced 16-byte loads (double buffered: the next chunk is in flight while the
+// current one feeds 32 MFMAs per wave), so every J element is fetched once per tile instead of once per block pair.
+__global__ __launch_bounds__(256) void k_normal_eq(const NormalEqArgs a) {
+  __shared__ float as[2][CH][TW];
+  __shared__ float bs[2][CH][TW];
+  __shared__ float cw[2][CH];
+  // XCD-aware decomposition: blockIdx % 8 selects the XCD (observed dispatch rule); all tiles of an instance share it
+  const int ntile = (a.nblk + 1) / 2;
+  const int ntp = ntile * (ntile + 1) / 2;
   const int xcd = blockIdx.x & 7;
-  const int slot = blockIdx.x >> 3;          // index within this XCD's share
-  const int inst_in_xcd = slot / npair;
-  const int pair = slot % npair;
-  const int b = inst_in_xcd * 8 + xcd;
+  const int slot = blockIdx.x >> 3;
+  const int b = (slot / ntp) * 8 + xcd;
+  const int tp = slot % ntp;
   if (b >= a.B) return;
   if (a.active != nullptr && a.active[b] == 0) return;
-  // pair -> (bi >= bj)
-  int bi = 0;
-  while ((bi + 1) * (bi + 2) / 2 <= pair) ++bi;
-  const int bj = pair - bi * (bi + 1) / 2;
+  int ti = 0;
+  while ((ti + 1) * (ti + 2) / 2 <= tp) ++ti;
+  const int tj = tp - ti * (ti + 1) / 2;
 
-  const int lane = threadIdx.x & 63;
-  const int ws = threadIdx.x >> 6;           // K-split index of this wave
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c = lane & 31, h = lane >> 5;
-  const int colA = bi * 32 + c, colB = bj * 32 + c;
-  const bool okA = colA < a.ldJ, okB = colB < a.ldJ;
+  const int bi = 2 * ti + (wv >> 1), bj = 2 * tj + (wv & 1);
+  const bool work = bi < a.nblk && bj < a.nblk && bi >= bj;          // blocks above the diagonal / past the end idle
   const int rcol = a.L + 7;
+  // staging role of this thread: row (tid / 32 + 8 k), 16-byte chunk (tid % 32): chunks 0..15 A strip, 16..31 B strip
+  const int srow = tid >> 5, sch = tid & 31;
+  const bool sideB = sch >= 16;
+  const int scol = (sideB ? tj : ti) * TW + (sch & 15) * 4;
 
   f32x16 acc;
 #pragma unroll
@@ -71,42 +79,50 @@ __global__ __launch_bounds__(64 * KSPLIT) void k_normal_eq(const NormalEqArgs a)
     if (n <= 0 || nd <= 0) continue;
     const float scale = sg.weight / (float)nd;
     const float* base = sg.rows + (size_t)b * sg.inst_stride + (size_t)sg.row_offset * a.ldJ;
-    // software pipeline: the 12 loads of this wave's next row group are issued before the 4 MFMAs of the current one
-    auto load_step = [&](int r0, float (&av)[4], float (&bv)[4]) {
+    const int nchunk = (n + CH - 1) / CH;
+    f32x4 st[8];
+    float sres = 0.f;
+    auto fetch = [&](int ch) {                 // global -> registers (issued one chunk ahead)
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const int row = r0 + 4 * h + t;
-        const bool ok = row < n;
-        const float* rp = base + (size_t)row * a.ldJ;
-        const float res = ok ? rp[rcol] : 0.f;
-        const float va = (ok && okA) ? rp[colA] : 0.f;
-        const float vb = (ok && okB) ? rp[colB] : 0.f;
-        av[t] = va;
-        bv[t] = vb * (scale * huber_rho(res, sg.robust_th));
+      for (int k = 0; k < 8; ++k) {
+        const int row = ch * CH + srow + 8 * k;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (row < n && scol < a.ldJ) v = *reinterpret_cast<const f32x4*>(base + (size_t)row * a.ldJ + scol);
+        st[k] = v;
       }
+      if (tid < CH) { const int row = ch * CH + tid; sres = row < n ? base[(size_t)row * a.ldJ + rcol] : 0.f; }
     };
-    float av[4], bv[4], an[4], bn[4];
-    const int stride = 8 * KSPLIT;
-    load_step(8 * ws, av, bv);
-    for (int r0 = 8 * ws; r0 < n; r0 += stride) {
-      if (r0 + stride < n) load_step(r0 + stride, an, bn);
+    auto stash = [&](int buf, int ch) {        // registers -> LDS
 #pragma unroll
-      for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bv[t], acc, 0, 0, 0);
+      for (int k = 0; k < 8; ++k) {
+        float* dst = sideB ? &bs[buf][srow + 8 * k][(sch & 15) * 4] : &as[buf][srow + 8 * k][(sch & 15) * 4];
+        *reinterpret_cast<f32x4*>(dst) = st[k];
+      }
+      if (tid < CH) cw[buf][tid] = (ch * CH + tid < n) ? scale * huber_rho(sres, sg.robust_th) : 0.f;
+    };
+    fetch(0);
+    __syncthreads();                           // previous segment's readers are done with both buffers
+    stash(0, 0);
+    for (int ch = 0; ch < nchunk; ++ch) {
+      const int buf = ch & 1;
+      if (ch + 1 < nchunk) fetch(ch + 1);
+      __syncthreads();                         // chunk `ch` visible in LDS; buffer buf^1 free
+      if (work) {
 #pragma unroll
-      for (int t = 0; t < 4; ++t) { av[t] = an[t]; bv[t] = bn[t]; }
+        for (int g = 0; g < CH / 8; ++g) {
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const int r = 8 * g + 4 * h + t;
+            const float av = as[buf][r][(wv >> 1) * 32 + c];
+            const float bv = bs[buf][r][(wv & 1) * 32 + c] * cw[buf][r];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+          }
+        }
+      }
+      if (ch + 1 < nchunk) stash(buf ^ 1, ch + 1);
     }
   }
-  // fixed-order reduction of the KSPLIT partial accumulators (wave 0 adds waves 1, 2, 3 in that order)
-  if (ws > 0) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) part[ws - 1][r][lane] = acc[r];
-  }
-  __syncthreads();
-  if (ws == 0) {
-#pragma unroll
-    for (int w2 = 0; w2 < KSPLIT - 1; ++w2)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[r] += part[w2][r][lane];
+  if (work) {
     float* H = a.Hext + (size_t)b * a.ldJ * a.ldJ;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -125,10 +141,11 @@ int launch_normal_eq(const RowSegment* segs, int n_seg, int L, int B, const int*
   for (int i = 0; i < 3; ++i) a.seg[i] = segs[i < n_seg ? i : 0];
   a.n_seg = n_seg; a.L = L; a.ldJ = L + POSE_PAD; a.nblk = L / 32 + 1; a.B = B; a.active = d_active;
   a.Hext = d_Hext;
-  const int npair = a.nblk * (a.nblk + 1) / 2;
+  const int ntile = (a.nblk + 1) / 2;
+  const int ntp = ntile * (ntile + 1) / 2;
   const int inst_per_xcd = (B + 7) / 8;
-  const int grid = inst_per_xcd * npair * 8;
-  hipLaunchKernelGGL(k_normal_eq, dim3(grid), dim3(64 * KSPLIT), 0, stream, a);
+  const int grid = inst_per_xcd * ntp * 8;
+  hipLaunchKernelGGL(k_normal_eq, dim3(grid), dim3(256), 0, stream, a);
   HM_CHECK_HIP(hipGetLastError());
   return 0;
 }
