@@ -81,7 +81,6 @@ struct RenderBuffers {
   float* yG;               // [B][nG_stride]
   float* JR;               // [B][2*F*R][ldJ]   depth rows then mask rows
   int nR_stride, nG_stride;
-  int overflow_flag_unused;
 };
 
 int launch_latent_bias(const hm_decoder_s* dec, const float* d_latent, int ld_latent, const int* d_active,

@@ -30,7 +30,7 @@ struct hm_workspace_s {
   float *ptsS, *JS, *yS;
   float* Hext;
   float* Lfac;
-  int *active, *nS_dummy;
+  int* active;
   RenderBuffers rb;
   // optional timing of the dominant launch (SDF-term K1) with HIP events on the caller's stream
   int profile_on;
@@ -155,7 +155,7 @@ extern "C" int hm_workspace_create(hm_decoder_s* dec, const hm_limits* lim, hm_w
       lim->max_samples < 0 || lim->max_samples > 64 || lim->max_frames > 64) {
     hm_set_error("bad limits (need batch>0, points>0, frames<=64, samples<=64)"); return -1; }
   hm_workspace_s* w = new hm_workspace_s();
-  w->profile_on = 0; w->ev_used = 0; w->d_blob = nullptr; w->blob_bytes = 0; w->nS_dummy = nullptr;
+  w->profile_on = 0; w->ev_used = 0; w->d_blob = nullptr; w->blob_bytes = 0;
   w->dec = dec; w->lim = *lim; w->L = dec->L; w->ldJ = dec->L + POSE_PAD;
   if (w->lim.max_frames == 0 || w->lim.max_rays == 0 || w->lim.max_samples == 0) {
     w->lim.max_frames = 1; w->lim.max_rays = 1; w->lim.max_samples = 2;     // shape-only workspace

@@ -134,3 +134,19 @@ def test_config3_many_instances_sharded_single_rank():
     for i in range(64):
         assert torch.equal(lat[i].cpu(), direct[i].latent) and torch.equal(T[i].cpu(), direct[i].T_ow)
     assert torch.equal(lat[:20].cpu(), lat[140:160].cpu())          # instance i and i+20k are the same fruit
+
+
+def test_odd_batch_sizes_match_singles():
+    """Batch sizes that do not divide the XCD / tile decompositions (B = 1, 7, 100): every instance of the batch
+    equals its single-instance run bit for bit (K4 instance->XCD map, K1 tile-major order, ragged tails)."""
+    from hortimapping_amd import optimizer as HO, workloads as W
+    opt = W.c2_opt_cfg(max_iter=4)
+    dec, od, dicts = make(32, 1, 0.04, (1.0, 0.75, 1.3), list(range(7)), n_pts=200, n_frames=1, n_fg=40, n_bg=24)
+    singles = [HO.optimize_batch(dec, opt, [W.to_instance(d)])[0] for d in dicts]
+    for B in (7, 100):
+        res = HO.optimize_batch(dec, opt, [W.to_instance(dicts[i % 7]) for i in range(B)])
+        assert len(res) == B
+        for i, r in enumerate(res):
+            s = singles[i % 7]
+            assert r.iter_count == s.iter_count == 4
+            assert torch.equal(r.latent, s.latent) and torch.equal(r.T_ow, s.T_ow)
