@@ -160,6 +160,11 @@ int hm_render_residuals(hm_workspace_t ws, const hm_opt_cfg* cfg, const hm_batch
                         const float* d_frame_override, float* d_rows, int* d_V, int* d_ray_row, int* d_counts,
                         void* stream);
 
+/* ---- performance-analysis aids (not part of the drop-in surface): when a device buffer is registered, block 0 of
+ * the f16x3 decoder kernel / of the solve kernel writes shader-clock stamps per stage into it (scripts/gpu_trace_*.py). */
+void hm_debug_set_trace(long long* d_buf);      /* [NSTAGE * 4 + 1] or NULL */
+void hm_debug_set_k5_trace(long long* d_buf);   /* [6] or NULL */
+
 /* ---- next row: iso-surface of a decoded SDF grid; replaces convert_sdf_voxels_to_mesh
  * (wild_completion/utils.py:565-588, scikit-image marching cubes on the host) by marching tetrahedra on the GPU over the
  * same grid.  d_sdf [B][n^3] with index (ix*n + iy)*n + iz (the layout create_voxel_grid produces, utils.py:542-562);

@@ -150,3 +150,23 @@ def test_odd_batch_sizes_match_singles():
             s = singles[i % 7]
             assert r.iter_count == s.iter_count == 4
             assert torch.equal(r.latent, s.latent) and torch.equal(r.T_ow, s.T_ow)
+
+
+@pytest.mark.parametrize("L", [64, 128])
+def test_intermediate_latent_sizes_full_loop(L):
+    """The whole loop (K1, K4, K5, render chain) for latent sizes between the shipped 32 and the benchmark's 256,
+    including a degenerate instance (no surface points, no frames -> 'submap not valid' at iteration 0)."""
+    from hortimapping_amd import optimizer as HO, workloads as W
+    opt = W.c2_opt_cfg(max_iter=5)
+    dec, od, dicts = make(L, 4, 0.04, (1.0, 0.75, 1.3), [0, 1], n_pts=300, n_frames=1, n_fg=48, n_bg=48)
+    insts = [W.to_instance(d, pose_known=True) for d in dicts]
+    empty = W.to_instance(dicts[0], pose_known=True)
+    empty.points_w = empty.points_w[:0]
+    empty.render_data = {k: [] for k in empty.render_data}
+    res = HO.optimize_batch(dec, opt, insts + [empty])
+    for d, r in zip(dicts, res[:2]):
+        z, T, n = oracle_run(od, opt, d, True, ("L", L, d["id"]))
+        assert r.iter_count == n == 5
+        assert rel(r.latent, z) < 2e-3 and rel(r.T_ow, T) < 1e-4
+    assert res[2].status == 16 and res[2].iter_count == 0
+    assert torch.equal(res[2].latent, empty.latent) and torch.equal(res[2].T_ow, empty.T_ow)
