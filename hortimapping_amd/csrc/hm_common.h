@@ -40,6 +40,7 @@ struct StageDescH {
   const void* wp;      // packed [(mb - mb_lo)][k16 step][hi|lo][64 lanes][8 halves]
   int n_k16;           // K steps of 16
   float unscale;       // 2^-shift: accumulators hold 2^shift * (W X)
+  int mb_stride;       // distance between row blocks in 16-byte units (n_k16 * 128 + pad)
 };
 
 struct DecoderDev {

@@ -38,6 +38,10 @@ struct DecodeArgsH {
   long long* trace;    // optional [NSTAGE][4] shader-clock stamps of block 0 / wave 0 (perf analysis), or nullptr
 };
 
+#ifndef HM_DIAG
+#define HM_DIAG 0  // 1..3: timing-only experiments (results are garbage), see scripts/diag_k1h.sh
+#endif
+
 constexpr float LO_SCALE = 2048.f;          // 2^11
 constexpr float LO_UNSCALE = 1.f / 2048.f;
 
@@ -67,6 +71,10 @@ __device__ __forceinline__ void mfma_step_h(f32x16 (&acc)[2][2], const f16x8& a0
                                             const f16x8& a1h, const f16x8& a1l, const f16x8& b0h,
                                             const f16x8& b1h, const f16x8& b0l, const f16x8& b1l) {
   const _Float16 cs = (_Float16)LO_UNSCALE;
+#if HM_DIAG == 1  // loads only: consume every operand with one VALU op each, no matrix work
+  acc[0][0][0] += (float)(a0h[0] + a0l[0] + a1h[0] + a1l[0]) + (float)(b0h[0] + b1h[0] + b0l[0] + b1l[0]);
+  return;
+#endif
   if (U0) {
     const f16x8 a0c = a0h * cs;
     acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, b0h, acc[0][0], 0, 0, 0);
@@ -90,12 +98,19 @@ __device__ __forceinline__ void mfma_step_h(f32x16 (&acc)[2][2], const f16x8& a0
 // K loop.  Weights (A, from L2) are fetched TWO K-steps ahead into a ring of three statically named register sets,
 // activations (B, from LDS) one step ahead into a ring of two; the loop is unrolled by six so every set has a fixed
 // name (no register rotation => hipcc emits counted waits instead of draining vmcnt/lgkmcnt each step), and
-// sched_barriers keep each prefetch above the MFMAs it overlaps (hipcc otherwise sinks loads to their first use).
+// sched_barriers pin each prefetch between the MFMAs it overlaps (hipcc otherwise sinks loads to their first use).
+// HM_DIAG = 1 / 2 / 3 build timing-only variants (loads only / L1-resident weights / no weight fetches) that were
+// used to attribute the loop time (scripts/diag_k1h.sh); results are garbage in those builds.
 struct ASet { f16x8 h0, l0, h1, l1; };
 struct BSet { f16x8 h0, h1, l0, l1; };
 
 template <bool U0, bool U1>
 __device__ __forceinline__ void load_a(ASet& a, const f16x8* __restrict__ wp0, const f16x8* __restrict__ wp1, int k) {
+#if HM_DIAG == 2  // every weight fetch hits the same lines (L1-resident): isolates the L2 stream
+  k = 0;
+#elif HM_DIAG == 3  // no weight fetches after the first: matrix pipe + LDS only
+  if (k > 1) return;
+#endif
   if (U0) { a.h0 = wp0[k * 128]; a.l0 = wp0[k * 128 + 64]; }
   if (U1) { a.h1 = wp1[k * 128]; a.l1 = wp1[k * 128 + 64]; }
 }
@@ -105,6 +120,67 @@ __device__ __forceinline__ void load_b(BSet& b, const f16x8* xh, const f16x8* xl
   b.l0 = xl[k * 2 * TQ + xo]; b.l1 = xl[k * 2 * TQ + xo + 32];
 }
 
+#define HM_MFMA(A, B, C) C = __builtin_amdgcn_mfma_f32_32x32x16_f16(A, B, C, 0, 0, 0)
+#define HM_FENCE() __builtin_amdgcn_sched_barrier(0)
+
+// One K-step with its prefetches woven BETWEEN the MFMAs (pairs of MFMAs, then one or two memory instructions): a
+// wave that has to wait for a slot in the shared vector-memory / LDS queues does so in the shadow of its own MFMAs
+// instead of in front of them.  Activation reads (needed next step) go first, weight fetches (needed two steps on) last.
+template <bool U0, bool U1>
+__device__ __forceinline__ void step_h(f32x16 (&acc)[2][2], const ASet& a, const BSet& b, ASet& an, BSet& bn,
+                                       const f16x8* __restrict__ wp0, const f16x8* __restrict__ wp1, int ka,
+                                       const f16x8* xh, const f16x8* xl, int kb, int xo) {
+  const _Float16 cs = (_Float16)LO_UNSCALE;
+#if HM_DIAG == 2
+  ka = 0;
+#endif
+  const f16x8* w0 = wp0 + ka * 128;
+  const f16x8* w1 = wp1 + ka * 128;
+  const f16x8* ph = xh + kb * 2 * TQ + xo;
+  const f16x8* pl = xl + kb * 2 * TQ + xo;
+#if HM_DIAG == 3
+#define HM_LDA(dst, src)
+#else
+#define HM_LDA(dst, src) dst = src
+#endif
+#define HM_LDB(dst, src) dst = src
+  if (U0 && U1) {
+    const f16x8 a0c = a.h0 * cs;
+    const f16x8 a1c = a.h1 * cs;
+    HM_FENCE();
+    HM_MFMA(a.h0, b.h0, acc[0][0]); HM_MFMA(a.h0, b.h1, acc[0][1]);
+    HM_FENCE(); HM_LDB(bn.h0, ph[0]); HM_LDB(bn.h1, ph[32]); HM_FENCE();
+    HM_MFMA(a.h1, b.h0, acc[1][0]); HM_MFMA(a.h1, b.h1, acc[1][1]);
+    HM_FENCE(); HM_LDB(bn.l0, pl[0]); HM_LDB(bn.l1, pl[32]); HM_FENCE();
+    HM_MFMA(a0c, b.l0, acc[0][0]); HM_MFMA(a0c, b.l1, acc[0][1]);
+    HM_FENCE(); HM_LDA(an.h0, w0[0]); HM_FENCE();
+    HM_MFMA(a1c, b.l0, acc[1][0]); HM_MFMA(a1c, b.l1, acc[1][1]);
+    HM_FENCE(); HM_LDA(an.l0, w0[64]); HM_FENCE();
+    HM_MFMA(a.l0, b.h0, acc[0][0]); HM_MFMA(a.l0, b.h1, acc[0][1]);
+    HM_FENCE(); HM_LDA(an.h1, w1[0]); HM_FENCE();
+    HM_MFMA(a.l1, b.h0, acc[1][0]); HM_MFMA(a.l1, b.h1, acc[1][1]);
+    HM_FENCE(); HM_LDA(an.l1, w1[64]); HM_FENCE();
+  } else if (U0) {
+    const f16x8 a0c = a.h0 * cs;
+    HM_FENCE();
+    HM_MFMA(a.h0, b.h0, acc[0][0]); HM_MFMA(a.h0, b.h1, acc[0][1]);
+    HM_FENCE(); bn.h0 = ph[0]; bn.h1 = ph[32]; bn.l0 = pl[0]; bn.l1 = pl[32]; HM_FENCE();
+    HM_MFMA(a0c, b.l0, acc[0][0]); HM_MFMA(a0c, b.l1, acc[0][1]);
+    HM_FENCE(); an.h0 = w0[0]; an.l0 = w0[64]; HM_FENCE();
+    HM_MFMA(a.l0, b.h0, acc[0][0]); HM_MFMA(a.l0, b.h1, acc[0][1]);
+    HM_FENCE();
+  } else {
+    const f16x8 a1c = a.h1 * cs;
+    HM_FENCE();
+    HM_MFMA(a.h1, b.h0, acc[1][0]); HM_MFMA(a.h1, b.h1, acc[1][1]);
+    HM_FENCE(); bn.h0 = ph[0]; bn.h1 = ph[32]; bn.l0 = pl[0]; bn.l1 = pl[32]; HM_FENCE();
+    HM_MFMA(a1c, b.l0, acc[1][0]); HM_MFMA(a1c, b.l1, acc[1][1]);
+    HM_FENCE(); an.h1 = w1[0]; an.l1 = w1[64]; HM_FENCE();
+    HM_MFMA(a.l1, b.h0, acc[1][0]); HM_MFMA(a.l1, b.h1, acc[1][1]);
+    HM_FENCE();
+  }
+}
+
 template <bool U0, bool U1>
 __device__ __forceinline__ void gemm_loop_h(f32x16 (&acc)[2][2], const f16x8* __restrict__ wp0,
                                             const f16x8* __restrict__ wp1, int n_k16, const f16x8* xh,
@@ -112,19 +188,31 @@ __device__ __forceinline__ void gemm_loop_h(f32x16 (&acc)[2][2], const f16x8* __
   const int xo = (lane >> 5) * TQ + (lane & 31);
   const int last = n_k16 - 1;
   ASet a0 = {}, a1 = {}, a2 = {};
-  BSet b0, b1;
+  BSet b0, b1 = {};
   load_a<U0, U1>(a0, wp0, wp1, 0);
   load_a<U0, U1>(a1, wp0, wp1, last < 1 ? last : 1);
   load_b(b0, xh, xl, 0, xo);
+#if HM_DIAG == 1 || defined(HM_BUNCHED)
 #define HM_STEP(AS, BS, ANEXT, BNEXT, I)                                                         \
-  if (ks + (I) < n_k16) {                                                                        \
+  if (HM_COND(I)) {                                                                              \
     load_a<U0, U1>(ANEXT, wp0, wp1, (ks + (I) + 2 < n_k16) ? ks + (I) + 2 : last);               \
     load_b(BNEXT, xh, xl, (ks + (I) + 1 < n_k16) ? ks + (I) + 1 : last, xo);                     \
     __builtin_amdgcn_sched_barrier(0);                                                           \
     mfma_step_h<U0, U1>(acc, AS.h0, AS.l0, AS.h1, AS.l1, BS.h0, BS.h1, BS.l0, BS.l1);            \
     __builtin_amdgcn_sched_barrier(0);                                                           \
   }
-  for (int ks = 0; ks < n_k16; ks += 6) {
+#else
+#define HM_STEP(AS, BS, ANEXT, BNEXT, I)                                                         \
+  if (HM_COND(I)) {                                                                              \
+    step_h<U0, U1>(acc, AS, BS, ANEXT, BNEXT, wp0, wp1, (ks + (I) + 2 < n_k16) ? ks + (I) + 2 : last, xh, xl, \
+                   (ks + (I) + 1 < n_k16) ? ks + (I) + 1 : last, xo);                            \
+  }
+#endif
+  // full groups of six run branch-free: with a conditional per step hipcc's wait-count pass merges the "step
+  // skipped" paths and emits vmcnt(1) where vmcnt(4+) is right, which cuts the two-step prefetch distance to one
+  int ks = 0;
+#define HM_COND(I) true
+  for (; ks + 6 <= n_k16; ks += 6) {
     HM_STEP(a0, b0, a2, b1, 0)
     HM_STEP(a1, b1, a0, b0, 1)
     HM_STEP(a2, b0, a1, b1, 2)
@@ -132,6 +220,16 @@ __device__ __forceinline__ void gemm_loop_h(f32x16 (&acc)[2][2], const f16x8* __
     HM_STEP(a1, b0, a0, b1, 4)
     HM_STEP(a2, b1, a1, b0, 5)
   }
+#undef HM_COND
+#define HM_COND(I) (ks + (I) < n_k16)
+  if (ks < n_k16) {
+    HM_STEP(a0, b0, a2, b1, 0)
+    HM_STEP(a1, b1, a0, b0, 1)
+    HM_STEP(a2, b0, a1, b1, 2)
+    HM_STEP(a0, b1, a2, b0, 3)
+    HM_STEP(a1, b0, a0, b1, 4)
+  }
+#undef HM_COND
 #undef HM_STEP
 }
 
@@ -253,8 +351,8 @@ __global__ __launch_bounds__(512, 2) void k_decoder_h(const DecodeArgsH a) {
 
     {
       const f16x8* wp = reinterpret_cast<const f16x8*>(sh.wp);
-      const f16x8* wp0 = wp + (size_t)(mb0 - sd.mb_lo) * sh.n_k16 * 128 + lane;
-      const f16x8* wp1 = wp + (size_t)(mb1 - sd.mb_lo) * sh.n_k16 * 128 + lane;
+      const f16x8* wp0 = wp + (size_t)(mb0 - sd.mb_lo) * sh.mb_stride + lane;
+      const f16x8* wp1 = wp + (size_t)(mb1 - sd.mb_lo) * sh.mb_stride + lane;
       if (u0 && u1) gemm_loop_h<true, true>(acc, wp0, wp1, sh.n_k16, xh, xl, lane);
       else if (u0) gemm_loop_h<true, false>(acc, wp0, wp1, sh.n_k16, xh, xl, lane);
       else if (u1) gemm_loop_h<false, true>(acc, wp0, wp1, sh.n_k16, xh, xl, lane);
@@ -262,6 +360,7 @@ __global__ __launch_bounds__(512, 2) void k_decoder_h(const DecodeArgsH a) {
     if (tr) a.trace[s * 4 + 1] = clock64();
     __syncthreads();
     if (tr) a.trace[s * 4 + 2] = clock64();
+
 
     if (MODE == 0 || epi <= EPI_FWD7) {
       const float* bias = bl + s * HID;

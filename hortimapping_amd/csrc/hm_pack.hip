@@ -59,7 +59,7 @@ size_t pack_stage(Blob& blob, int mb_lo, int mb_hi, int n_kg, const std::functio
 // fp16 hi/lo packing of a stage for the f16x3 kernel.  With shift s (2^s * max|A| < 32768):
 //   hi = fp16(A * 2^s),  lo = fp16(A * 2^s - hi);   the kernel forms  hi*Xh + (hi*2^-11)*(Xl*2^11) + lo*Xh.
 // Layout [mb][k16][hi|lo][lane][8]: lane l holds row l&31, k = 16*step + 8*(l>>5) + j.
-size_t pack_stage_h(std::vector<uint16_t>& blob, int mb_lo, int mb_hi, int n_k16,
+size_t pack_stage_h(std::vector<uint16_t>& blob, int mb_lo, int mb_hi, int n_k16, int mb_stride,
                     const std::function<float(int, int)>& A, float* unscale) {
   const int n_mb = mb_hi - mb_lo;
   float mx = 0.f;
@@ -69,7 +69,7 @@ size_t pack_stage_h(std::vector<uint16_t>& blob, int mb_lo, int mb_hi, int n_k16
   while (shift > -12 && ldexpf(mx, shift) >= 32768.f) --shift;
   *unscale = ldexpf(1.f, -shift);
   size_t off = (blob.size() + 63) & ~size_t(63);
-  blob.resize(off + (size_t)n_mb * n_k16 * 2 * 64 * 8, 0);
+  blob.resize(off + (size_t)n_mb * mb_stride * 8, 0);
   for (int mbi = 0; mbi < n_mb; ++mbi)
     for (int ks = 0; ks < n_k16; ++ks)
       for (int lane = 0; lane < 64; ++lane)
@@ -79,7 +79,7 @@ size_t pack_stage_h(std::vector<uint16_t>& blob, int mb_lo, int mb_hi, int n_k16
           const float v = ldexpf(A(r, c), shift);
           const __half hi = __float2half_rn(v);
           const __half lo = __float2half_rn(v - __half2float(hi));
-          const size_t base = off + ((((size_t)mbi * n_k16 + ks) * 2) * 64 + lane) * 8 + j;
+          const size_t base = off + ((size_t)mbi * mb_stride + ((size_t)ks * 2) * 64 + lane) * 8 + j;
           blob[base] = *reinterpret_cast<const uint16_t*>(&hi);
           blob[base + 64 * 8] = *reinterpret_cast<const uint16_t*>(&lo);
         }
@@ -118,7 +118,8 @@ extern "C" int hm_decoder_create(int latent_dim, const float* const* W, const fl
       const int n_k16 = (kmax + 15) / 16;
       auto Ap = [&](int r, int c) { return c < kmax ? A(r, c) : 0.f; };
       sth[s].n_k16 = n_k16;
-      hoff[s] = pack_stage_h(hblob, lo, hi, n_k16, Ap, &sth[s].unscale);
+      sth[s].mb_stride = n_k16 * 128;
+      hoff[s] = pack_stage_h(hblob, lo, hi, n_k16, sth[s].mb_stride, Ap, &sth[s].unscale);
     }
     pend[s].has_bias = 0;
     if (bfun) {
