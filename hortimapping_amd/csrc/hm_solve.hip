@@ -81,10 +81,25 @@ __device__ void exp_pose(const float* x, bool sim3, float* T) {
   T[12] = 0.f; T[13] = 0.f; T[14] = 0.f; T[15] = 1.f;
 }
 
+// fp64 wave reduction on DPP lane moves (quad swaps, half-mirror, mirror give every lane its 16-lane row total; the
+// four row totals are then combined through readlane) -- __shfl_xor on a double costs two ds_bpermute round trips per
+// step, which made the reduction, not the loads, the critical path of the residual sweep.
+template <int CTRL>
+__device__ __forceinline__ double dpp_move(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double rdlane_d(double v, int l) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
 __device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  return v;
+  v += dpp_move<0xB1>(v);    // quad_perm [1,0,3,2]
+  v += dpp_move<0x4E>(v);    // quad_perm [2,3,0,1]
+  v += dpp_move<0x141>(v);   // row_half_mirror
+  v += dpp_move<0x140>(v);   // row_mirror
+  return (rdlane_d(v, 0) + rdlane_d(v, 16)) + (rdlane_d(v, 32) + rdlane_d(v, 48));
 }
 
 }  // namespace
@@ -163,6 +178,7 @@ __global__ __launch_bounds__(NT) void k_solve_update(const SolveArgs a) {
   __shared__ float xvec[NBK * 32];
   __shared__ float rv[NBK * 32];
   __shared__ float diagA[NBK * 32];
+  __shared__ double cs[NBK * 32], rs[NBK * 32];   // fp64 column / row sums of the refinement residual
   __shared__ float red[NT / 64];
   __shared__ float red2[NT / 64];
   __shared__ int flag;
@@ -367,15 +383,48 @@ __global__ __launch_bounds__(NT) void k_solve_update(const SolveArgs a) {
   if (trc) g_k5_trace[3] = clock64();
   for (int i = tid; i < E; i += NT) xvec[i] = rv[i];
   __syncthreads();
-  for (int i = wv; i < E; i += NT / 64) {
-    double sd = 0.0;
-    for (int k = lane; k < E; k += 64) {
-      const float aik = (k == i) ? diagA[i] : (k < i ? H[(size_t)i * ld + k] : H[(size_t)k * ld + i]);
-      sd += (double)aik * (double)xvec[k];
+  // r = b - A x in fp64 from the fp32 system.  Only the lower triangle of H is valid; one sweep over it with
+  // row-contiguous (coalesced) reads serves both halves of the symmetric product: element H[i][k] (k < i) adds
+  // H[i][k] x[k] to row i (wave reduction) and H[i][k] x[i] to column k (per-lane accumulators, merged with LDS fp64
+  // atomics at the end).  Eleven rows per wave (a third of its share) are in flight at a time to cover the load latency.
+  for (int k = tid; k < NBK * 32; k += NT) { cs[k] = k < E ? (double)diagA[k] * (double)xvec[k] : 0.0; rs[k] = 0.0; }
+  __syncthreads();
+  {
+    constexpr int NCH = (MAX_E + 63) / 64, RU = 11;
+    double colacc[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) colacc[c] = 0.0;
+    for (int i0 = wv; i0 < E; i0 += (NT / 64) * RU) {
+      float h[RU][NCH];
+#pragma unroll
+      for (int u = 0; u < RU; ++u) {
+        const int i = i0 + (NT / 64) * u;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+          const int k = lane + 64 * c;
+          h[u][c] = (i < E && k < i) ? H[(size_t)i * ld + k] : 0.f;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < RU; ++u) {
+        const int i = i0 + (NT / 64) * u;
+        const double xi = i < E ? (double)xvec[i] : 0.0;
+        double sd = 0.0;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+          sd += (double)h[u][c] * (double)xvec[lane + 64 * c];
+          colacc[c] += (double)h[u][c] * xi;
+        }
+        sd = wave_sum(sd);
+        if (lane == 0 && i < E) rs[i] = sd;
+      }
     }
-    sd = wave_sum(sd);
-    if (lane == 0) rv[i] = (float)((double)bvec[i] - sd);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+      if (lane + 64 * c < E) atomicAdd(&cs[lane + 64 * c], colacc[c]);
   }
+  __syncthreads();
+  for (int i = tid; i < E; i += NT) rv[i] = (float)((double)bvec[i] - (rs[i] + cs[i]));
   __syncthreads();
   if (trc) g_k5_trace[4] = clock64();
   solve_packed(Lp, rv, E, tid);
