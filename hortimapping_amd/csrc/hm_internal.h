@@ -63,9 +63,11 @@ struct RenderBuffers {
   // workspace
   float* frame;            // [B][F][16]  T_oc (12) | d_min | d_max | range | pad
   int* valid_count;        // [B][F]
-  int* nRq;                // [B] samples to decode = n_frames * R * M
-  float* ptsR;             // [B][nR_stride][4]
-  float* sdfR;             // [B][nR_stride]
+  int* nRq;                // [B] ball-valid samples to decode (K_v, loss.py:38-49)
+  float* ptsR;             // [B][nR_stride][4]  all samples, (frame, ray, depth) order, w = ball-valid flag
+  float* ptsRc;            // [B][nR_stride][4]  the ball-valid ones, compacted (what the decoder reads)
+  int* cpos;               // [B][nR_stride]     sample -> slot in ptsRc / sdfR, -1 if not ball-valid
+  float* sdfR;             // [B][nR_stride]     decoder output, compacted order
   int* keepcnt;            // [B][F*R]
   unsigned long long* keepmask;  // [B][F*R]
   float* res_d;            // [B][F*R]

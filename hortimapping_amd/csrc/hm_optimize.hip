@@ -70,6 +70,8 @@ void carve(hm_workspace_s* w, Carver& c) {
   rb.valid_count = c.take<int>((size_t)B * F);
   rb.nRq = c.take<int>(B);
   rb.ptsR = c.take<float>((size_t)B * w->nR_stride * 4);
+  rb.ptsRc = c.take<float>((size_t)B * w->nR_stride * 4);
+  rb.cpos = c.take<int>((size_t)B * w->nR_stride);
   rb.sdfR = c.take<float>((size_t)B * w->nR_stride);
   rb.keepcnt = c.take<int>(B * nray);
   rb.keepmask = c.take<unsigned long long>(B * nray);
@@ -138,7 +140,7 @@ int render_pass(hm_workspace_s* ws, const RenderCfg& rc, const RenderBuffers& rb
   const int B = bt->B;
   int rc_ = launch_render_front(rc, rb, bt->d_T_ow, d_active, B, st, d_frame_override);
   if (rc_) return rc_;
-  rc_ = launch_decoder(ws->dec, B, rb.ptsR, rb.nRq, d_active, ws->nR_stride, ws->c0, ws->c4, rb.sdfR, nullptr, 0, 0, 0, st);
+  rc_ = launch_decoder(ws->dec, B, rb.ptsRc, rb.nRq, d_active, ws->nR_stride, ws->c0, ws->c4, rb.sdfR, nullptr, 0, 0, 0, st);
   if (rc_) return rc_;
   rc_ = launch_render_scan(rc, rb, d_active, B, st);
   if (rc_) return rc_;

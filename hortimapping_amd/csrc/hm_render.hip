@@ -5,7 +5,7 @@
 // depth sample (M <= 64) -- instead of the reference's where/boolean-index/unique/scatter_add sequence:
 //   k_frame_setup      optimizer.py:66,103-111   T_oc, depth window, per-frame constants
 //   k_sample_rays      loss.py:30-40             p_c = dir * d_j, p_o = R_oc p_c + t_oc, ball filter (+ count for :43-45)
-//   (K1 forward-only decodes all samples)        loss.py:48-49
+//   (K1 forward-only on the ball-valid samples)   loss.py:48-49
 //   k_ray_scan         loss.py:55-176            occupancy, transmittance scan, d_u, occ_ray, de/do, dm/do, do/ds,
 //                                                min-grad and occlusion filters, residuals
 //   k_ray_offsets      loss.py:160-166           torch.unique(ray ids) == ascending ray order -> prefix sums
@@ -61,7 +61,7 @@ __global__ void k_frame_setup(const RenderCfg cfg, const RenderBuffers rb, const
   if (active != nullptr && active[b] == 0) return;
   const int f = threadIdx.x;
   const int nf = rb.n_frames[b];
-  if (f == 0) rb.nRq[b] = nf * cfg.R * cfg.M;
+  if (f == 0) rb.nRq[b] = 0;                 // k_sample_rays counts the ball-valid samples into it
   if (f >= cfg.F) return;
   rb.valid_count[b * cfg.F + f] = 0;
   if (f >= nf) return;
@@ -96,19 +96,25 @@ __global__ void k_frame_setup(const RenderCfg cfg, const RenderBuffers rb, const
   fp[15] = 0.f;
 }
 
-__global__ void k_sample_rays(const RenderCfg cfg, const RenderBuffers rb, const int* __restrict__ active) {
+// Sample points of every ray, ball filter, and compaction of the ball-valid ones: like the reference (loss.py:38-49)
+// only those go through the decoder.  Slots are handed out per 256-sample block (wave ballots + one atomic on the
+// instance counter); the slot order between blocks depends on scheduling, which is harmless: the decoder treats every
+// query column independently, so a sample's sdf does not depend on its slot.
+__global__ __launch_bounds__(256) void k_sample_rays(const RenderCfg cfg, const RenderBuffers rb,
+                                                     const int* __restrict__ active) {
+  __shared__ int wcount[4];
+  __shared__ int base_s;
   const int b = blockIdx.z, f = blockIdx.y;
   if (active != nullptr && active[b] == 0) return;
   if (f >= rb.n_frames[b]) return;
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;     // (ray, sample)
   const int total = cfg.R * cfg.M;
-  if (idx >= total) return;
   const int r = idx / cfg.M, j = idx - r * cfg.M;
   const int nray = rb.n_fg[b * cfg.F + f] + rb.n_bg[b * cfg.F + f];
   const float* fp = rb.frame + ((size_t)b * cfg.F + f) * 16;
   f32x4 o = {0, 0, 0, 0};
   bool valid = false;
-  if (r < nray) {
+  if (idx < total && r < nray) {
     const float* dir = rb.rays + (((size_t)b * cfg.F + f) * cfg.R + r) * 3;
     const float d = linspace_at(fp[12], fp[13], cfg.M, j);                      // optimizer.py:111
     const float x = dir[0] * d, y = dir[1] * d, z = dir[2] * d;                 // loss.py:30
@@ -118,9 +124,27 @@ __global__ void k_sample_rays(const RenderCfg cfg, const RenderBuffers rb, const
     valid = sqrtf(o[0] * o[0] + o[1] * o[1] + o[2] * o[2]) < fp[14];            // loss.py:38
     o[3] = valid ? 1.f : 0.f;
   }
-  reinterpret_cast<f32x4*>(rb.ptsR)[(size_t)b * rb.nR_stride + (size_t)f * total + idx] = o;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const unsigned long long m = __ballot(valid);
-  if ((threadIdx.x & 63) == 0 && m != 0ull) atomicAdd(&rb.valid_count[b * cfg.F + f], __popcll(m));
+  const int before = __popcll(m & ((1ull << lane) - 1ull));
+  if (lane == 0) wcount[wv] = __popcll(m);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int nblk = wcount[0] + wcount[1] + wcount[2] + wcount[3];
+    base_s = nblk > 0 ? atomicAdd(&rb.nRq[b], nblk) : 0;
+    if (nblk > 0) atomicAdd(&rb.valid_count[b * cfg.F + f], nblk);
+  }
+  __syncthreads();
+  if (idx >= total) return;
+  int slot = -1;
+  if (valid) {
+    slot = base_s + before;
+    for (int w2 = 0; w2 < wv; ++w2) slot += wcount[w2];
+    reinterpret_cast<f32x4*>(rb.ptsRc)[(size_t)b * rb.nR_stride + slot] = o;
+  }
+  const size_t at = (size_t)b * rb.nR_stride + (size_t)f * total + idx;
+  reinterpret_cast<f32x4*>(rb.ptsR)[at] = o;
+  rb.cpos[at] = slot;
 }
 
 // one wavefront per ray, lane = depth sample
@@ -151,7 +175,8 @@ __global__ __launch_bounds__(256) void k_ray_scan(const RenderCfg cfg, const Ren
   bool valid = false;
   if (in) {
     valid = rb.ptsR[(sbase + lane) * 4 + 3] != 0.f;
-    s = rb.sdfR[sbase + lane];
+    const int slot = rb.cpos[sbase + lane];
+    s = slot >= 0 ? rb.sdfR[(size_t)b * rb.nR_stride + slot] : 0.f;
     dj = linspace_at(d_min, d_max, M, lane);
     if (valid) {
       if (cfg.log_occ) o = 1.f / (1.f + expf(s / sigma));                       // utils.py:136-142 sigmoid(-s/sigma)
