@@ -37,7 +37,7 @@ def unpack_records(rec: torch.Tensor, L: int):
 def gather_records(local: torch.Tensor, n_total: int) -> torch.Tensor:
     """All-gather the per-rank record blocks into the global (n_total, W) matrix, in instance order.
     One collective: ranks pad their block to ceil(n_total / world) rows (all_gather_into_tensor needs equal sizes)."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return local
     world = dist.get_world_size()
     per = math.ceil(n_total / world)
