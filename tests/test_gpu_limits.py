@@ -1,0 +1,57 @@
+"""Edges of the operator's envelope on the GPU: the maximum ray-sample count (64 = one wavefront lane per sample),
+ragged frame / ray / point counts inside one batch (padding must never leak into results), and the error behaviour of
+the C ABI when a request exceeds the workspace limits (status code + hm_last_error text, never a crash)."""
+import os
+
+import pytest
+import torch
+
+from test_gpu_configs import make, oracle_run, rel
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(params=["f32", "f16x3"], autouse=True, scope="module")
+def precision(request):
+    os.environ["HM_PRECISION"] = request.param
+    yield request.param
+    os.environ.pop("HM_PRECISION", None)
+
+
+def test_max_samples_and_ragged_batch_vs_oracle():
+    from hortimapping_amd import optimizer as HO, workloads as W
+    opt = W.c2_opt_cfg(max_iter=4, n_sample_on_ray=64, n_frame=8)
+    shapes = [dict(n_pts=130, n_frames=1, n_fg=20, n_bg=9), dict(n_pts=700, n_frames=3, n_fg=64, n_bg=31),
+              dict(n_pts=65, n_frames=6, n_fg=7, n_bg=50)]
+    insts, refs = [], []
+    for j, kw in enumerate(shapes):
+        dec, od, dicts = make(32, 4, 0.04, (1.0, 0.75, 1.3), [10 + j], **kw)
+        insts.append(W.to_instance(dicts[0], pose_known=True))
+        refs.append((od, dicts[0]))
+    res = HO.optimize_batch(dec, opt, insts)
+    singles = [HO.optimize_batch(dec, opt, [i])[0] for i in insts]
+    for j, (r, s, (od, d)) in enumerate(zip(res, singles, refs)):
+        assert torch.equal(r.latent, s.latent) and torch.equal(r.T_ow, s.T_ow)      # padding-independent, bit for bit
+        z, T, n = oracle_run(od, opt, d, True, ("lim", j))
+        assert r.iter_count == n == 4
+        assert rel(r.latent, z) < 2e-3 and rel(r.T_ow, T) < 1e-4
+
+
+def test_requests_beyond_the_workspace_limits_fail_loudly():
+    from hortimapping_amd import _lib, optimizer as HO, workloads as W
+    dec, od, dicts = make(32, 4, 0.04, (1.0, 0.75, 1.3), [0, 1], n_pts=100, n_frames=1, n_fg=8, n_bg=8)
+    insts = [W.to_instance(d) for d in dicts]
+    dev = torch.device("cuda")
+    pb = HO.PackedBatch(insts, 32, 1, dev, joint=True)
+    with pytest.raises(_lib.HortiHipError, match="limits"):
+        HO.Workspace(dec, 2, pb.points_stride, pb.F, pb.R, 65)                      # more samples than wavefront lanes
+    ws = HO.Workspace(dec, 1, pb.points_stride, pb.F, pb.R, 16)                     # workspace sized for ONE instance
+    with pytest.raises(_lib.HortiHipError, match="exceeds workspace limit"):
+        HO.run_packed(ws, HO.opt_cfg_from_dict(W.c2_opt_cfg(max_iter=2)), pb, 0)
+    ws2 = HO.Workspace(dec, 2, pb.points_stride, pb.F, pb.R, 16)
+    with pytest.raises(_lib.HortiHipError, match="n_sample_on_ray"):
+        HO.run_packed(ws2, HO.opt_cfg_from_dict(W.c2_opt_cfg(max_iter=2, n_sample_on_ray=32)), pb, 0)
+    # the handles stay usable after a refused call
+    HO.run_packed(ws2, HO.opt_cfg_from_dict(W.c2_opt_cfg(max_iter=2)), pb, 0)
+    torch.cuda.synchronize()
+    assert int(pb.iter_count.min()) == 2
