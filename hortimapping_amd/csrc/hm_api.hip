@@ -13,6 +13,9 @@ extern "C" int hm_decode_batch(const hm_decoder_s* dec, int B, const float* d_la
   if (mode == 1 && (d_J == nullptr || ldJ < dec->L + POSE_PAD || (ldJ % 4) != 0)) {
     hm_set_error("hm_decode_batch: Jacobian buffer needs ldJ >= L + %d and ldJ %% 4 == 0", POSE_PAD); return -1; }
   if (pose_dim != 0 && pose_dim != 6 && pose_dim != 7) { hm_set_error("pose_dim must be 0, 6 or 7"); return -1; }
+  if (n_stride <= 0 || (n_stride % TQ) != 0) {
+    hm_set_error("hm_decode_batch: n_stride %d must be a positive multiple of %d", n_stride, TQ); return -1; }
+  if (ld_latent < dec->L) { hm_set_error("hm_decode_batch: ld_latent %d < latent size %d", ld_latent, dec->L); return -1; }
   if (B <= 0) return 0;
   hipStream_t st = static_cast<hipStream_t>(stream);
   float* c0 = d_cbias;

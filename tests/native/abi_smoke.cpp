@@ -1,0 +1,79 @@
+// Stand-alone consumer of libhortihip.so: no Python, no torch -- only the public header, the HIP runtime for the
+// caller-owned device buffers, and the C ABI.  Builds an analytic decoder (every hidden unit i < 3 of layer 0 copies one
+// coordinate, the rest of the network passes it on), decodes a handful of points in both arithmetics and checks the
+// closed form  sdf = tanh(w * relu(x + y + z... ))  -- see the comments below.  Prints ABI_SMOKE_OK on success.
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdio>
+#include <vector>
+#include "hortimapping_amd.h"
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); return 2; } } while (0)
+#define HM(x) do { int r_ = (x); if (r_ != 0) { printf("hm error %d at %d: %s\n", r_, __LINE__, hm_last_error()); return 3; } } while (0)
+
+int main() {
+  const int L = 32, H = 512, D0 = L + 3, m = H - D0;
+  // lin0: h_i = relu(c_i) for i < 3 (c = x, y, z), h_3 = relu(z_0) (first latent), others 0
+  std::vector<float> W0((size_t)H * D0, 0.f), W1((size_t)H * H, 0.f), W3((size_t)m * H, 0.f), W4((size_t)H * H, 0.f),
+      W8(H, 0.f), bz(H, 0.f), b8(1, 0.1f);
+  for (int c = 0; c < 3; ++c) W0[(size_t)c * D0 + L + c] = 1.f;
+  W0[(size_t)3 * D0 + 0] = 1.f;
+  for (int i = 0; i < H; ++i) W1[(size_t)i * H + i] = 1.f;          // identity: lin1, lin2, lin5..7
+  for (int i = 0; i < m; ++i) W3[(size_t)i * H + i] = 1.f;          // lin3 keeps units 0..m-1
+  for (int i = 0; i < m; ++i) W4[(size_t)i * H + i] = 1.f;          // lin4 passes h3 through, ignores the skip input
+  W8[0] = 0.5f; W8[1] = 0.25f; W8[2] = -1.f; W8[3] = 2.f;           // sdf = tanh(.5 x+ + .25 y+ - z+ + 2 z0+ + .1)
+  const float* Ws[9] = {W0.data(), W1.data(), W1.data(), W3.data(), W4.data(), W1.data(), W1.data(), W1.data(), W8.data()};
+  std::vector<float> b3(m, 0.f);
+  const float* bs[9] = {bz.data(), bz.data(), bz.data(), b3.data(), bz.data(), bz.data(), bz.data(), bz.data(), b8.data()};
+  hm_decoder_t dec = nullptr;
+  HM(hm_decoder_create(L, Ws, bs, &dec));
+  if (hm_decoder_latent_dim(dec) != L) { printf("latent dim\n"); return 4; }
+
+  const int B = 2, NS = 64, ldJ = L + 8;
+  std::vector<float> lat((size_t)B * L, 0.f), pts((size_t)B * NS * 4, 0.f);
+  lat[0] = 0.3f; lat[L] = -0.7f;                                    // z0 of instance 0 / 1
+  int nq_h[B] = {5, 3};
+  for (int b = 0; b < B; ++b)
+    for (int i = 0; i < nq_h[b]; ++i) {
+      float* p = &pts[((size_t)b * NS + i) * 4];
+      p[0] = 0.1f * (i + 1) * (b ? -1.f : 1.f); p[1] = 0.05f * i; p[2] = 0.02f * (i - 1);
+    }
+  float *d_lat, *d_pts, *d_cb, *d_y, *d_J; int* d_nq;
+  CK(hipMalloc(&d_lat, lat.size() * 4)); CK(hipMalloc(&d_pts, pts.size() * 4)); CK(hipMalloc(&d_cb, 2 * B * 512 * 4));
+  CK(hipMalloc(&d_y, B * NS * 4)); CK(hipMalloc(&d_J, (size_t)B * NS * ldJ * 4)); CK(hipMalloc(&d_nq, B * 4));
+  CK(hipMemcpy(d_lat, lat.data(), lat.size() * 4, hipMemcpyHostToDevice));
+  CK(hipMemcpy(d_pts, pts.data(), pts.size() * 4, hipMemcpyHostToDevice));
+  CK(hipMemcpy(d_nq, nq_h, B * 4, hipMemcpyHostToDevice));
+  hipStream_t st; CK(hipStreamCreate(&st));
+  for (int prec = 0; prec < 2; ++prec) {
+    HM(hm_decoder_set_precision(dec, prec));
+    CK(hipMemsetAsync(d_J, 0, (size_t)B * NS * ldJ * 4, st));
+    HM(hm_decode_batch(dec, B, d_lat, L, d_pts, d_nq, NS, d_cb, d_y, d_J, ldJ, 7, 1, st));
+    CK(hipStreamSynchronize(st));
+    std::vector<float> y(B * NS), J((size_t)B * NS * ldJ);
+    CK(hipMemcpy(y.data(), d_y, y.size() * 4, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(J.data(), d_J, J.size() * 4, hipMemcpyDeviceToHost));
+    for (int b = 0; b < B; ++b)
+      for (int i = 0; i < nq_h[b]; ++i) {
+        const float* p = &pts[((size_t)b * NS + i) * 4];
+        auto rl = [](float v) { return v > 0.f ? v : 0.f; };
+        const float z0 = lat[(size_t)b * L];
+        const float a = 0.5f * rl(p[0]) + 0.25f * rl(p[1]) - rl(p[2]) + 2.f * rl(z0) + 0.1f;
+        const float want = std::tanh(a), dy = 1.f - want * want;
+        const float gx = dy * 0.5f * (p[0] > 0), gz0 = dy * 2.f * (z0 > 0);
+        const float* row = &J[((size_t)b * NS + i) * ldJ];
+        if (std::fabs(y[b * NS + i] - want) > 2e-6f || std::fabs(row[L + 7] - want) > 2e-6f ||
+            std::fabs(row[L] - gx) > 2e-6f || std::fabs(row[0] - gz0) > 2e-6f) {
+          printf("mismatch prec %d b %d i %d: y %.8f want %.8f dx %.8f want %.8f dz0 %.8f want %.8f\n", prec, b, i,
+                 y[b * NS + i], want, row[L], gx, row[0], gz0);
+          return 5;
+        }
+      }
+  }
+  // a refused request must come back as an error code with a message, not a crash
+  if (hm_decode_batch(dec, B, d_lat, L, d_pts, d_nq, 63, d_cb, d_y, d_J, ldJ, 7, 1, st) == 0) { printf("stride 63 accepted\n"); return 6; }
+  if (hm_last_error() == nullptr || hm_last_error()[0] == 0) { printf("no error text\n"); return 7; }
+  HM(hm_decoder_destroy(dec));
+  printf("ABI_SMOKE_OK\n");
+  return 0;
+}

@@ -8,6 +8,8 @@ reference.  Tolerances are relative to the largest reference magnitude and state
     pose_known); free-pose trajectories are only bounded loosely because the reference's own iteration map is
     discontinuous and amplifies 1e-7 perturbations to 1e-2 (SURVEY.md 8d "parity noise floor").
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -16,6 +18,7 @@ from tests.golden_util import (cfg_from_golden, decoder_params, list_golden, loa
                                render_data_from_golden)
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 _CACHE = {}
 
@@ -261,3 +264,16 @@ def test_batched_equals_single_and_order_preserved():
         assert torch.equal(rb.latent, rr.latent) and torch.equal(rb.T_ow, rr.T_ow)
     assert batch[1].status == 16 and batch[1].iter_count == 0
     assert len({r.iter_count for r in batch}) > 2            # they really stopped at different iterations
+
+
+def test_native_consumer_of_the_c_abi(tmp_path):
+    """tests/native/abi_smoke.cpp: a stand-alone C++ program (public header + HIP runtime only, no Python, no torch)
+    builds an analytic decoder, decodes in both arithmetics through hm_decode_batch and checks the closed form."""
+    import subprocess
+    exe = str(tmp_path / "abi_smoke")
+    libdir = os.path.join(ROOT, "hortimapping_amd")
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O1", "-std=c++17", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "native", "abi_smoke.cpp"), "-o", exe,
+                           "-L", libdir, "-lhortihip", "-Wl,-rpath," + libdir])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "ABI_SMOKE_OK" in r.stdout, r.stdout + r.stderr
