@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libhortihip.so")
 SOURCES = ["hm_pack.hip", "hm_decoder.hip", "hm_decoder_h.hip", "hm_normal_eq.hip", "hm_solve.hip", "hm_render.hip",
-           "hm_optimize.hip", "hm_mesh.hip", "hm_api.hip"]
+           "hm_optimize.hip", "hm_mesh.hip", "hm_metrics.hip", "hm_api.hip"]
 
 
 def _stale():

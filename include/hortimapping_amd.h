@@ -173,6 +173,12 @@ void hm_debug_set_k5_trace(long long* d_buf);   /* [6] or NULL */
 int hm_extract_surface(int B, const float* d_sdf, int n, float level, float cube_radius, int* d_offsets,
                        int* d_tri_count, float* d_tris, int max_tris, void* stream);
 
+/* ---- evaluation primitive: nearest-neighbour distances, the query under ChamferDistance
+ * (metrics_3d/chamfer_distance.py:16-26) and PrecisionRecall (metrics_3d/precision_recall.py:13-50), which use an
+ * Open3D KD-tree per point.  Exact brute-force scan: d_dist[i] = min_j |a_i - b_j| (Euclidean, not squared).
+ * d_a4 [na][4], d_b4 [nb][4]: xyz + one ignored pad float per point; centre both clouds first (fp32 differences). */
+int hm_nn_distance(const float* d_a4, int na, const float* d_b4, int nb, float* d_dist, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
