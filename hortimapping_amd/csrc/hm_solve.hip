@@ -179,6 +179,8 @@ __global__ __launch_bounds__(NT) void k_solve_update(const SolveArgs a) {
   __shared__ float rv[NBK * 32];
   __shared__ float diagA[NBK * 32];
   __shared__ double cs[NBK * 32], rs[NBK * 32];   // fp64 column / row sums of the refinement residual
+  __shared__ __attribute__((aligned(16))) float colk[32];
+  __shared__ float dinv[32];
   __shared__ float red[NT / 64];
   __shared__ float red2[NT / 64];
   __shared__ int flag;
@@ -276,13 +278,23 @@ __global__ __launch_bounds__(NT) void k_solve_update(const SolveArgs a) {
       bool bad = false;
 #pragma unroll
       for (int k = 0; k < 32; ++k) {
-        const float piv = rdlane(ar[k], k);
+        colk[cc] = ar[k];
+        __builtin_amdgcn_wave_barrier();
+        const float piv = colk[k];
         bad |= !(piv > 0.f);
-        const float d = sqrtf(piv);
-        const float inv = 1.f / d;
-        ar[k] = (cc == k) ? d : ar[k] * inv;
+        float y = __builtin_amdgcn_rsqf(piv);
+        y = y * fmaf(-0.5f * piv * y, y, 1.5f);
+        const float t = -ar[k] * (y * y);
 #pragma unroll
-        for (int j = k + 1; j < 32; ++j) ar[j] = fmaf(-ar[k], rdlane(ar[k], j), ar[j]);
+        for (int g = (k + 1) / 4; g < 8; ++g) {
+          const f32x4 v = reinterpret_cast<const f32x4*>(colk)[g];
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (4 * g + e > k) ar[4 * g + e] = fmaf(t, v[e], ar[4 * g + e]);
+        }
+        __builtin_amdgcn_wave_barrier();
+        ar[k] = (cc == k) ? piv * y : ar[k] * y;
+        if (lane == k) dinv[k] = y;
         __builtin_amdgcn_sched_barrier(0);
       }
       if (bad) flag = 1;
