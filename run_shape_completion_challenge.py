@@ -38,8 +38,8 @@ def main(config):
     deepsdf_baseline = cfg["baseline_name"] == "DeepSDF"
     mesh_extractor = MeshExtractor(decoder, code_len=code_len, voxels_dim=voxels_dim, cube_radius=object_radius_max_m)
     opt = Optimizer(cfg, decoder, mesh_extractor, None)
-    cd_metric = ChamferDistance()
-    pr_metric = PrecisionRecall(min_t=0.001, max_t=0.01, num=100)          # :83
+    cd_metric = ChamferDistance(backend="gpu")                            # 1,000,000-point clouds: hm_nn_distance
+    pr_metric = PrecisionRecall(min_t=0.001, max_t=0.01, num=100, backend="gpu")          # :83
     data = DS.ShapeCompletionDataset(cfg["data_dir"], cfg["split"])
     result_folder = os.path.join(cfg["data_dir"], "results", cfg["run_name"], cfg["split"])
     os.makedirs(result_folder, exist_ok=True)
