@@ -55,3 +55,26 @@ def test_requests_beyond_the_workspace_limits_fail_loudly():
     HO.run_packed(ws2, HO.opt_cfg_from_dict(W.c2_opt_cfg(max_iter=2)), pb, 0)
     torch.cuda.synchronize()
     assert int(pb.iter_count.min()) == 2
+
+
+def test_frame_without_enough_ball_samples_is_skipped_like_the_reference():
+    """One of three frames looks past the fruit (fewer than min_valid_sample = 100 ball-valid samples): the reference's
+    compute_render_loss returns None for it and the iteration goes on with the other frames (optimizer.py:130-132);
+    a second instance in the same batch keeps all its frames."""
+    from hortimapping_amd import optimizer as HO, workloads as W
+    opt = W.c2_opt_cfg(max_iter=4, n_sample_on_ray=16, n_frame=3)
+    dec, od, dicts = make(32, 4, 0.04, (1.0, 0.75, 1.3), [20, 21], n_pts=400, n_frames=3, n_fg=60, n_bg=40)
+    off = dicts[0]["render"]["T_wc"][1].copy()
+    off[0, 3] += 0.6                                    # camera 1 of instance 0 moved 60 cm sideways: rays miss the ball
+    dicts[0]["render"]["T_wc"][1] = off
+    insts = [W.to_instance(d, pose_known=True) for d in dicts]
+    dbg = {}
+    res = HO.optimize_batch(dec, opt, insts, debug=dbg)
+    counts = dbg["counts"].cpu()                         # [K_v, K_g, V, -] of the last iteration
+    full = HO.optimize_batch(dec, opt, [W.to_instance(dicts[1], pose_known=True)])[0]
+    assert torch.equal(res[1].latent, full.latent)
+    for j, (r, d) in enumerate(zip(res, dicts)):
+        z, T, n = oracle_run(od, opt, d, True, ("skipframe", j))
+        assert r.iter_count == n == 4 and r.status == 8
+        assert rel(r.latent, z) < 2e-3 and rel(r.T_ow, T) < 1e-4
+    assert int(counts[0, 0]) < int(counts[1, 0])         # the skipped frame's samples are not counted for instance 0
