@@ -285,6 +285,11 @@ __global__ __launch_bounds__(512, 2) void k_decoder_h(const DecodeArgsH a) {
   f32x16 acc[2][2];
   float gx0 = 0.f, gx1 = 0.f, gx2 = 0.f;
   float y_keep = 0.f;
+  // Largest |value| this lane ever stored into the fp16 activation planes.  fp16 tops out at 65504: beyond it the hi
+  // part becomes inf, the next ReLU turns the resulting NaN into 0 and the network would silently compute garbage.
+  // A tile that overflowed is poisoned instead (NaN sdf, NaN Jacobian rows), which the solver reports as
+  // HM_STATUS_SOLVE_FAILED; the exact fp32 arithmetic (precision 0) has no such limit.
+  float xmax = 0.f;
   const float* cbias0 = a.c0 + (size_t)b * HID;
   const float* cbias4 = a.c4 + (size_t)b * HID;
   // stage all forward biases in LDS: the epilogues then never wait on global memory
@@ -385,6 +390,7 @@ __global__ __launch_bounds__(512, 2) void k_decoder_h(const DecodeArgsH a) {
               bits |= (pos ? 1u : 0u) << (nb * 16 + 4 * g + j);
               v[j] = pos ? val : 0.f;
             }
+            xmax = fmaxf(xmax, fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])));
             if (epi == EPI_FWD3) {
               const f32x4 p = pts4[qbase + nb * 32 + qa];
 #pragma unroll
@@ -416,6 +422,7 @@ __global__ __launch_bounds__(512, 2) void k_decoder_h(const DecodeArgsH a) {
 #pragma unroll
           for (int j = 0; j < 4; ++j) { part = fmaf(x[4 + j], w1[j], part); }
         }
+        if (__any(!(xmax < 65504.f))) part = __builtin_nanf("");
         sc[w * 64 + lane] = part;
         __syncthreads();
         float a8 = 0.f;
@@ -490,6 +497,7 @@ __global__ __launch_bounds__(512, 2) void k_decoder_h(const DecodeArgsH a) {
 #pragma unroll
             for (int j = 0; j < 4; ++j)
               v[j] = ((bits >> (nb * 16 + 4 * g + j)) & 1u) ? acc[sl][nb][4 * g + j] * us : 0.f;
+            xmax = fmaxf(xmax, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
             split_store(xh4, xl4, ((f4 >> 3) * TQ + nb * 32 + qa) * 2 + hi, v);
           }
         }
@@ -517,6 +525,7 @@ __global__ __launch_bounds__(512, 2) void k_decoder_h(const DecodeArgsH a) {
 
   if (a.trace != nullptr && blockIdx.x == 0 && tid == 0) a.trace[n_stage * 4] = clock64();
   if (MODE == 0) return;
+  if (__any(!(xmax < 65504.f))) gx0 = __builtin_nanf("");
   sc[(w * 4 + 0) * 64 + lane] = gx0;
   sc[(w * 4 + 1) * 64 + lane] = gx1;
   sc[(w * 4 + 2) * 64 + lane] = gx2;

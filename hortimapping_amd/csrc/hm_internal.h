@@ -30,6 +30,7 @@ struct SolveArgs {
   float* T_ow;             // [B][16]
   const int* pose_known;   // [B] or nullptr
   const int* V;            // [B] depth-render residual count (joint mode) or nullptr (shape-only)
+  const int* nflag;        // [B] set when a ball-valid ray sample decoded to a non-finite sdf (joint mode) or nullptr
   int* active;             // [B]
   int* iter_count;         // [B]
   int* status;             // [B]
@@ -62,6 +63,7 @@ struct RenderBuffers {
   const float* cube_radius;// [B]
   // workspace
   float* frame;            // [B][F][16]  T_oc (12) | d_min | d_max | range | pad
+  int* nflag;              // [B] numerical-failure flag of the render pass (non-finite sdf of a ball-valid sample)
   int* valid_count;        // [B][F]
   int* nRq;                // [B] ball-valid samples to decode (K_v, loss.py:38-49)
   float* ptsR;             // [B][nR_stride][4]  all samples, (frame, ray, depth) order, w = ball-valid flag

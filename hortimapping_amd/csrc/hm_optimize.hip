@@ -69,6 +69,7 @@ void carve(hm_workspace_s* w, Carver& c) {
   rb.frame = c.take<float>((size_t)B * F * 16);
   rb.valid_count = c.take<int>((size_t)B * F);
   rb.nRq = c.take<int>(B);
+  rb.nflag = c.take<int>(B);
   rb.ptsR = c.take<float>((size_t)B * w->nR_stride * 4);
   rb.ptsRc = c.take<float>((size_t)B * w->nR_stride * 4);
   rb.cpos = c.take<int>((size_t)B * w->nR_stride);
@@ -277,7 +278,7 @@ extern "C" int hm_optimize_batch(hm_workspace_s* ws, const hm_opt_cfg* cfg, cons
     SolveArgs sa;
     memset(&sa, 0, sizeof(sa));
     sa.Hext = ws->Hext; sa.Lfac = ws->Lfac; sa.latent = bt->d_latent; sa.T_ow = bt->d_T_ow;
-    sa.pose_known = bt->d_pose_known; sa.V = mode == 0 ? rb.V : nullptr;
+    sa.pose_known = bt->d_pose_known; sa.V = mode == 0 ? rb.V : nullptr; sa.nflag = mode == 0 ? rb.nflag : nullptr;
     sa.active = ws->active; sa.iter_count = bt->d_iter_count; sa.status = bt->d_status; sa.cur_scale = nullptr;
     sa.dbg_A = dbg ? dbg->d_A : nullptr; sa.dbg_b = dbg ? dbg->d_b : nullptr; sa.dbg_delta = dbg ? dbg->d_delta : nullptr;
     sa.L = L; sa.P = P; sa.ldJ = ws->ldJ; sa.ld_latent = L; sa.iter = it; sa.max_iter = cfg->max_iter;

@@ -61,7 +61,7 @@ __global__ void k_frame_setup(const RenderCfg cfg, const RenderBuffers rb, const
   if (active != nullptr && active[b] == 0) return;
   const int f = threadIdx.x;
   const int nf = rb.n_frames[b];
-  if (f == 0) rb.nRq[b] = 0;                 // k_sample_rays counts the ball-valid samples into it
+  if (f == 0) { rb.nRq[b] = 0; rb.nflag[b] = 0; }   // k_sample_rays counts the ball-valid samples into nRq
   if (f >= cfg.F) return;
   rb.valid_count[b * cfg.F + f] = 0;
   if (f >= nf) return;
@@ -177,6 +177,7 @@ __global__ __launch_bounds__(256) void k_ray_scan(const RenderCfg cfg, const Ren
     valid = rb.ptsR[(sbase + lane) * 4 + 3] != 0.f;
     const int slot = rb.cpos[sbase + lane];
     s = slot >= 0 ? rb.sdfR[(size_t)b * rb.nR_stride + slot] : 0.f;
+    if (valid && !isfinite(s)) rb.nflag[b] = 1;                 // reported by the solver as a numerical failure
     dj = linspace_at(d_min, d_max, M, lane);
     if (valid) {
       if (cfg.log_occ) o = 1.f / (1.f + expf(s / sigma));                       // utils.py:136-142 sigmoid(-s/sigma)

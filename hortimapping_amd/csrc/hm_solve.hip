@@ -190,10 +190,6 @@ __global__ __launch_bounds__(NT) void k_solve_update(const SolveArgs a) {
   if (a.active[b] == 0) return;
   const bool trc = g_k5_trace != nullptr && b == 0 && tid == 0;
   if (trc) g_k5_trace[0] = clock64();
-  if (a.V != nullptr && a.V[b] <= 0) {           // optimizer.py:139-141
-    if (tid == 0) { a.active[b] = 0; a.status[b] |= HM_STATUS_INVALID; }
-    return;
-  }
   const int L = a.L, P = a.P, E = L + P, ld = a.ldJ;
   const float* H = a.Hext + (size_t)b * ld * ld;
   float* Lg = a.Lfac + (size_t)b * LGS * LGS;
@@ -211,6 +207,23 @@ __global__ __launch_bounds__(NT) void k_solve_update(const SolveArgs a) {
   }
   if (tid == 0) flag = 0;
   __syncthreads();
+  // A non-finite normal matrix (e.g. activations beyond fp16 range in the f16x3 arithmetic) is a numerical failure
+  // and reported as such -- it must not pass for the reference's ordinary "submap not valid" exit below, which a
+  // NaN sdf would otherwise trigger (no with-grad sample survives a NaN comparison).
+  {
+    bool nf = false;
+    for (int i = tid; i < E; i += NT) nf |= !isfinite(diagA[i]) || !isfinite(bvec[i]);
+    if (nf || (a.nflag != nullptr && a.nflag[b] != 0)) flag = 1;
+  }
+  __syncthreads();
+  if (flag) {
+    if (tid == 0) { a.active[b] = 0; a.status[b] |= HM_STATUS_SOLVE_FAILED; }
+    return;
+  }
+  if (a.V != nullptr && a.V[b] <= 0) {           // optimizer.py:139-141
+    if (tid == 0) { a.active[b] = 0; a.status[b] |= HM_STATUS_INVALID; }
+    return;
+  }
   if (a.lm_on) {                                                // :220-225
     if (a.lm_eye) {
       float mx = -INFINITY;

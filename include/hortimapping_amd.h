@@ -45,7 +45,10 @@ int hm_decoder_latent_dim(hm_decoder_t dec);
 /* Arithmetic of the decoder GEMMs (the reference computes in fp32, optimizer.py:19):
  *   0  exact fp32 on the f32-input matrix cores (v_mfma_f32_32x32x2_f32; bitwise an fmaf chain)   [default]
  *   1  "f16x3": fp16 matrix cores with hi/lo split operands, three MFMA passes into one fp32 accumulator,
- *      ~2^-22 relative accuracy (fp32 class), 16/3 x the MFMA rate. */
+ *      ~2^-22 relative accuracy (fp32 class), 16/3 x the MFMA rate.  Hidden activations and back-propagated
+ *      gradients are held as fp16 hi/lo pairs, so they must stay below 65504 in magnitude; a 64-query tile that
+ *      exceeds it returns NaN sdf / Jacobian rows (never silent garbage) and hm_optimize_batch ends that instance
+ *      with HM_STATUS_SOLVE_FAILED.  Mode 0 has no such limit. */
 int hm_decoder_set_precision(hm_decoder_t dec, int precision);
 int hm_decoder_get_precision(hm_decoder_t dec);
 

@@ -277,3 +277,75 @@ def test_native_consumer_of_the_c_abi(tmp_path):
                            "-L", libdir, "-lhortihip", "-Wl,-rpath," + libdir])
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and "ABI_SMOKE_OK" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.parametrize("L", [32, 256])
+def test_dense_random_decoder_vs_fp64_oracle(L):
+    """A decoder with DENSE weights of trained-network statistics (He-normal rows, random weight-norm gains over two
+    decades, non-zero biases, a few tiny and a few large rows) instead of the near-identity synthetic fruit: exercises
+    the per-stage power-of-two scaling and the hi/lo split of the f16x3 arithmetic on generic data.  Errors are
+    measured against the fp64 oracle relative to the largest value of each output block.  (Hidden activations reach
+    ~10^3 here; f16x3 needs them below fp16's 65504 -- see test_f16x3_activation_overflow_is_reported.)"""
+    from hortimapping_amd import ops, synthetic as S
+    from hortimapping_amd.decoder import DecoderWeights
+    from oracle import hm_oracle as O
+    rs = np.random.RandomState(100 + L)
+    shp = S.layer_shapes(L, 512)
+    p = {"latent_dim": L, "hidden": 512}
+    for l, (o, i) in enumerate(shp):
+        w = rs.randn(o, i) * np.sqrt(2.0 / i)
+        if l < 8:
+            w[rs.randint(0, o, 6)] *= 1e-3                      # some almost-dead units
+            w[rs.randint(0, o, 6)] *= 8.0                       # some dominant ones
+            p[f"lin{l}.weight_v"] = w.astype(np.float32)
+            p[f"lin{l}.weight_g"] = (np.linalg.norm(w, axis=1, keepdims=True) *
+                                     10 ** rs.uniform(-0.25, 0.25, (o, 1))).astype(np.float32)
+            p[f"lin{l}.bias"] = (0.1 * rs.randn(o)).astype(np.float32)
+        else:
+            p["lin8.weight"] = (w * 0.002).astype(np.float32)
+            p["lin8.bias"] = np.array([0.01], dtype=np.float32)
+    gen = torch.Generator().manual_seed(7 * L)
+    B, n = 3, 192
+    lat = 0.1 * torch.randn(B, L, generator=gen)
+    pts = 0.05 * torch.randn(B, n, 3, generator=gen)
+    while True:                                                  # keep tanh out of saturation: 1 - y^2 in fp32 is
+        od = O.fold_decoder(p).to(torch.float64)                 # ill-conditioned there for ANY fp32 implementation
+        if float(O.decoder_forward(od, lat[0], pts[0]).abs().max()) < 0.5:
+            break
+        p["lin8.weight"] = p["lin8.weight"] * 0.5
+    dec = DecoderWeights.from_params(p)
+    pts4 = torch.zeros(B, n, 4)
+    pts4[..., :3] = pts
+    y, J = ops.decode_batch(dec, lat.cuda(), pts4.cuda(), torch.full((B,), n, dtype=torch.int32).cuda(), mode=1,
+                            pose_dim=0)
+    y, J = y.cpu().double(), J.cpu().double()
+    for b in range(B):
+        yo, go = O.decoder_jacobian(od, lat[b], pts[b])
+        assert torch.isfinite(y[b]).all() and torch.isfinite(J[b]).all()
+        assert float((y[b] - yo).abs().max() / yo.abs().max()) < 2e-5
+        assert float((J[b, :, :L] - go[:, :L]).abs().max() / go[:, :L].abs().max()) < 5e-5
+        assert float((J[b, :, L:L + 3] - go[:, L:]).abs().max() / go[:, L:].abs().max()) < 5e-5
+
+
+def test_f16x3_activation_overflow_is_reported():
+    """f16x3 stores activations as fp16 hi/lo pairs: a decoder whose hidden activations exceed 65504 cannot be run in
+    that arithmetic.  It must not return garbage silently: the instance ends with HM_STATUS_SOLVE_FAILED (non-finite
+    step), while the exact fp32 arithmetic optimises the same job."""
+    from hortimapping_amd import optimizer as HO, synthetic as S, workloads as W
+    from hortimapping_amd.decoder import DecoderWeights
+    p = S.make_synthetic_decoder(32, seed=3, r0=0.04, aniso=(1.0, 0.75, 1.3))
+    big = {k: (v.copy() if hasattr(v, "copy") else v) for k, v in p.items()}
+    big["lin1.weight_g"] = big["lin1.weight_g"] * 4.0e6           # layer-1 outputs ~1e5 ...
+    big["lin2.weight_g"] = big["lin2.weight_g"] / 4.0e6           # ... scaled back by layer 2: same function in fp32
+    Ws, bs = S.fold_weight_norm(p)
+    d = S.make_instance(Ws, bs, 32, 1, n_pts=256, n_frames=1, n_fg=16, n_bg=16)
+    inst = W.to_instance(d, pose_known=True)
+    opt = W.c2_opt_cfg(max_iter=3)
+    out = {}
+    for prec in ("f32", "f16x3"):
+        dec = DecoderWeights.from_params(big)
+        dec.set_precision(prec)
+        out[prec] = HO.optimize_batch(dec, opt, [inst])[0]
+    assert out["f32"].status == 8 and out["f32"].iter_count == 3 and torch.isfinite(out["f32"].latent).all()
+    assert out["f16x3"].status & 32 and out["f16x3"].iter_count < 3
+    assert torch.equal(out["f16x3"].latent, inst.latent)         # state left untouched by the failed step
