@@ -207,8 +207,10 @@ def main():
         "value": round(value, 3), "unit": "instances/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None,
-        "dtype": ("f32 results via f16x3: fp16 MFMA with hi/lo split operands, fp32 accumulate, ~2^-22 relative "
-                  "(same error vs the fp64 oracle as exact fp32)" if args.precision == "f16x3" else "f32"),
+        "dtype": args.precision,
+        "dtype_note": ("f16x3 = fp16 MFMA on hi/lo split operands (three passes per product), fp32 accumulate, results "
+                       "fp32-class: ~2^-22 relative, same error vs the fp64 oracle as exact fp32"
+                       if args.precision == "f16x3" else "f32 = exact fp32 MFMA (v_mfma_f32_32x32x2_f32)"),
         "data": "synthetic",
         "config": {
             "workload": ("c2_joint: 64 synthetic peppers per GPU, 256-dim latent, 8x512 DeepSDF decoder, "
