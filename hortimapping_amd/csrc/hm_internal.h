@@ -9,6 +9,7 @@
 #define HM_STATUS_MAX_ITER 8      // optimizer.py:289
 #define HM_STATUS_INVALID 16      // optimizer.py:139-141 "This submap is not valid"
 #define HM_STATUS_SOLVE_FAILED 32 // non-finite / non-SPD system (the reference would propagate NaN)
+#define HM_STATUS_FRAME_SKIPPED 64 // a frame returned None in some iteration (optimizer.py:130-132), informational
 
 namespace hm {
 
@@ -64,6 +65,7 @@ struct RenderBuffers {
   // workspace
   float* frame;            // [B][F][16]  T_oc (12) | d_min | d_max | range | pad
   int* nflag;              // [B] numerical-failure flag of the render pass (non-finite sdf of a ball-valid sample)
+  int* status;             // [B] per-instance status word of the running optimisation (nullptr outside of it)
   int* valid_count;        // [B][F]
   int* nRq;                // [B] ball-valid samples to decode (K_v, loss.py:38-49)
   float* ptsR;             // [B][nR_stride][4]  all samples, (frame, ray, depth) order, w = ball-valid flag

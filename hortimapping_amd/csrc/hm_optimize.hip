@@ -70,6 +70,7 @@ void carve(hm_workspace_s* w, Carver& c) {
   rb.valid_count = c.take<int>((size_t)B * F);
   rb.nRq = c.take<int>(B);
   rb.nflag = c.take<int>(B);
+  rb.status = nullptr;
   rb.ptsR = c.take<float>((size_t)B * w->nR_stride * 4);
   rb.ptsRc = c.take<float>((size_t)B * w->nR_stride * 4);
   rb.cpos = c.take<int>((size_t)B * w->nR_stride);
@@ -233,7 +234,7 @@ extern "C" int hm_optimize_batch(hm_workspace_s* ws, const hm_opt_cfg* cfg, cons
 
   RenderCfg rcfg = make_render_cfg(ws, cfg);
   RenderBuffers rb = ws->rb;
-  if (mode == 0) bind_inputs(rb, bt);
+  if (mode == 0) { bind_inputs(rb, bt); rb.status = bt->d_status; }
 
   for (int it = 0; it < cfg->max_iter; ++it) {
     rc = launch_latent_bias(ws->dec, bt->d_latent, L, ws->active, B, ws->c0, ws->c4, st);

@@ -162,6 +162,8 @@ __global__ __launch_bounds__(256) void k_ray_scan(const RenderCfg cfg, const Ren
   const bool frame_ok = f < rb.n_frames[b] && rb.valid_count[b * cfg.F + f] >= cfg.min_valid;   // loss.py:43-45
   if (!frame_ok || r >= nray) {
     if (lane == 0) { rb.keepcnt[rix] = 0; rb.keepmask[rix] = 0ull; }
+    if (lane == 0 && r == 0 && f < rb.n_frames[b] && !frame_ok && rb.status != nullptr)
+      atomicOr(&rb.status[b], HM_STATUS_FRAME_SKIPPED);          // 'This frame is not valid' (optimizer.py:130-132)
     return;
   }
   const int M = cfg.M;

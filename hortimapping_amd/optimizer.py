@@ -19,6 +19,7 @@ from . import _lib
 from .decoder import DecoderWeights
 
 STATUS_CONV_G, STATUS_CONV_C, STATUS_CONV_P, STATUS_MAX_ITER, STATUS_INVALID, STATUS_SOLVE_FAILED = 1, 2, 4, 8, 16, 32
+STATUS_FRAME_SKIPPED = 64       # informational: a frame was left out in some iteration (optimizer.py:130-132)
 
 _vp = ctypes.c_void_p
 
@@ -307,8 +308,11 @@ class Optimizer(object):
         """optimizer.py:28-302.  `latent` is updated in place AND returned, like the reference (:248,302)."""
         inst = Instance(latent, T_ow_torch, points_w_torch, render_data, float(cube_radius), bool(pose_known))
         res = self.optimize_batch([inst], shape_only=False)[0]
-        if res.status & STATUS_INVALID and self.log_on:
-            print("This submap is not valid")
+        if self.log_on:                                   # the reference's console messages (:131, :140)
+            if res.status & STATUS_FRAME_SKIPPED:
+                print("This frame is not valid")
+            if res.status & STATUS_INVALID:
+                print("This submap is not valid")
         latent.data.copy_(res.latent.to(latent.device, latent.dtype))
         return latent, res.T_ow.to(T_ow_torch.device, T_ow_torch.dtype), res.iter_count
 

@@ -31,6 +31,8 @@ typedef struct hm_workspace_s* hm_workspace_t;
 #define HM_STATUS_MAX_ITER 8      /* optimizer.py:289  maximum iteration number                      */
 #define HM_STATUS_INVALID 16      /* optimizer.py:139-141 'This submap is not valid' (no depth residual left) */
 #define HM_STATUS_SOLVE_FAILED 32 /* normal matrix not positive definite / non-finite step             */
+#define HM_STATUS_FRAME_SKIPPED 64 /* optimizer.py:130-132 'This frame is not valid': in some iteration a frame had
+                                      fewer than min_valid_sample ball-valid samples and was left out (informational) */
 
 const char* hm_last_error(void);
 

@@ -75,6 +75,6 @@ def test_frame_without_enough_ball_samples_is_skipped_like_the_reference():
     assert torch.equal(res[1].latent, full.latent)
     for j, (r, d) in enumerate(zip(res, dicts)):
         z, T, n = oracle_run(od, opt, d, True, ("skipframe", j))
-        assert r.iter_count == n == 4 and r.status == 8
+        assert r.iter_count == n == 4 and r.status == (8 | 64 if j == 0 else 8)     # 64 = HM_STATUS_FRAME_SKIPPED
         assert rel(r.latent, z) < 2e-3 and rel(r.T_ow, T) < 1e-4
     assert int(counts[0, 0]) < int(counts[1, 0])         # the skipped frame's samples are not counted for instance 0
