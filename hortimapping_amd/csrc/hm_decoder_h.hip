@@ -249,7 +249,8 @@ __global__ __launch_bounds__(512, 2) void k_decoder_h(const DecodeArgsH a) {
   __shared__ f16x8 xh[64 * TQ];    // 64 KiB: hi plane  X[k/8][q][8]
   __shared__ f16x8 xl[64 * TQ];    // 64 KiB: lo plane (scaled by 2^11)
   __shared__ float sc[2048 + 128];
-  __shared__ float bl[8 * HID];    // biases of the 8 forward stages (per-instance c0/c4 included), staged once per tile
+  __shared__ float bl[9 * HID];    // biases of the 8 forward stages (per-instance c0/c4 included) + lin8's weight row,
+                                   // staged once per tile: the epilogues never wait on global memory
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -293,6 +294,7 @@ __global__ __launch_bounds__(512, 2) void k_decoder_h(const DecodeArgsH a) {
   const float* cbias0 = a.c0 + (size_t)b * HID;
   const float* cbias4 = a.c4 + (size_t)b * HID;
   // stage all forward biases in LDS: the epilogues then never wait on global memory
+  bl[8 * HID + tid] = a.dec.w8[tid];
   for (int i = tid; i < 8 * HID; i += 512) {
     const StageDesc& sb = a.dec.st[i >> 9];
     const float* src = sb.inst_bias == 1 ? cbias0 : (sb.inst_bias == 2 ? cbias4 : sb.bias);
@@ -415,8 +417,8 @@ __global__ __launch_bounds__(512, 2) void k_decoder_h(const DecodeArgsH a) {
         for (int g = 0; g < 8; ++g) {
           float x[8];
           load_group(xh, xl, 8 * w + g, lane, x);
-          const f32x4 w0 = *reinterpret_cast<const f32x4*>(a.dec.w8 + 64 * w + 8 * g);
-          const f32x4 w1 = *reinterpret_cast<const f32x4*>(a.dec.w8 + 64 * w + 8 * g + 4);
+          const f32x4 w0 = *reinterpret_cast<const f32x4*>(bl + 8 * HID + 64 * w + 8 * g);
+          const f32x4 w1 = *reinterpret_cast<const f32x4*>(bl + 8 * HID + 64 * w + 8 * g + 4);
 #pragma unroll
           for (int j = 0; j < 4; ++j) { part = fmaf(x[j], w0[j], part); }
 #pragma unroll
@@ -445,7 +447,7 @@ __global__ __launch_bounds__(512, 2) void k_decoder_h(const DecodeArgsH a) {
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
             const int f4 = mb * 32 + 8 * g + 4 * hi;
-            const f32x4 wv = *reinterpret_cast<const f32x4*>(a.dec.w8 + f4);
+            const f32x4 wv = *reinterpret_cast<const f32x4*>(bl + 8 * HID + f4);
 #pragma unroll
             for (int nb = 0; nb < 2; ++nb) {
               const float dy = nb == 0 ? dyA : dyB;
