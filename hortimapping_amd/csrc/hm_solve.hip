@@ -115,10 +115,10 @@ __device__ __forceinline__ float rdlane(float v, int l) {
 // Triangular solves L y = r, L^T x = y on the packed factor in LDS whose DIAGONAL 32x32 blocks have been replaced by
 // their inverses: every block step is a 32x32 mat-vec (no serial chain) plus a workgroup-wide off-diagonal update.
 // `rv` holds the right-hand side on entry and the solution on exit.
-__device__ void solve_packed(const float* Lp, float* rv, int E, int tid) {
+__device__ void solve_packed(const float* Lp, float* rv, int E, int tid, bool forward = true) {
   const int lane = tid & 63, wv = tid >> 6;
   const int nblk = (E + 31) / 32;
-  for (int bb = 0; bb < nblk; ++bb) {                      // forward
+  for (int bb = 0; forward && bb < nblk; ++bb) {           // forward
     const int base = bb * 32;
     if (wv == 0) {
       const int i = base + (lane & 31);
@@ -251,6 +251,11 @@ __global__ __launch_bounds__(NT) void k_solve_update(const SolveArgs a) {
   if (trc) g_k5_trace[1] = clock64();
 
   // ---- blocked right-looking Cholesky, 32-column panels, trailing update on the fp32 matrix cores ----
+  // When the last 32-row block has a spare row (E not a multiple of 32, i.e. joint mode) the right-hand side rides
+  // along as row E of the bordered matrix [[A, b], [b^T, c]]: its Cholesky factor's row E IS y = L^-1 b, so the
+  // forward sweep of the first triangular solve costs one more panel row instead of nine barrier-separated block
+  // steps.  c only has to keep the last pivot positive (1e30).
+  const bool aug = (E & 31) != 0;
   // Wave w owns the lower-triangular 32x32 blocks p = w, w+8, ... (p = bi(bi+1)/2 + bk) in MFMA C layout.
   const int cc = lane & 31, hh = lane >> 5;
   f32x16 blk[NSLOT];
@@ -268,6 +273,8 @@ __global__ __launch_bounds__(NT) void k_solve_update(const SolveArgs a) {
       const int i = bi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh, k = bk * 32 + cc;
       float v = (i == k) ? 1.f : 0.f;                           // padding: identity
       if (bi < nblk && i < E && k < E) v = (i == k) ? diagA[i] : (k < i ? H[(size_t)i * ld + k] : H[(size_t)k * ld + i]);
+      if (aug && bi < nblk && (i == E || k == E))               // bordered system [[A, b], [b^T, c]], see below
+        v = (i == E && k == E) ? 1e30f : (i == E ? (k < E ? bvec[k] : 0.f) : (i < E ? bvec[i] : 0.f));
       blk[sl][r] = v;
     }
   }
@@ -402,9 +409,12 @@ __global__ __launch_bounds__(NT) void k_solve_update(const SolveArgs a) {
   __syncthreads();
 
   // ---- solve L L^T x = b (fp32), then one refinement step with an fp64 residual from the fp32 system ----
-  for (int i = tid; i < NBK * 32; i += NT) { rv[i] = i < E ? bvec[i] : 0.f; xvec[i] = 0.f; }
+  for (int i = tid; i < NBK * 32; i += NT) {
+    rv[i] = i < E ? (aug ? Lg[(size_t)E * LGS + i] : bvec[i]) : 0.f;     // aug: y = row E of the bordered factor
+    xvec[i] = 0.f;
+  }
   __syncthreads();
-  solve_packed(Lp, rv, E, tid);
+  solve_packed(Lp, rv, E, tid, !aug);
   if (trc) g_k5_trace[3] = clock64();
   for (int i = tid; i < E; i += NT) xvec[i] = rv[i];
   __syncthreads();
