@@ -382,25 +382,27 @@ __global__ __launch_bounds__(NT) void k_solve_update(const SolveArgs a) {
   for (int i = tid >> 5; i < E; i += NT / 32)
     for (int k = tid & 31; k <= i; k += 32) Lp[tri(i, k)] = Lg[(size_t)i * LGS + k];
   __syncthreads();
-  for (int bb = wv; bb < nblk; bb += NT / 64) {
-    // column `cc` of inverse(L11): x[k] = Linv[k][cc], forward substitution on e_cc with broadcast reads of L11
-    const int base = bb * 32;
-    float x[32];
+  {
+    // column `cc` of inverse(L11): x[k] = Linv[k][cc], forward substitution on e_cc with broadcast reads of L11.
+    // Each half-wave takes one diagonal block (blocks w and w + 8 in wave w): all nine blocks in a single pass.
+    const int bb = wv + (NT / 64) * hh;
+    if (bb < nblk) {
+      const int base = bb * 32;
+      float x[32];
 #pragma unroll
-    for (int k = 0; k < 32; ++k) {
-      const int i = base + k;
-      float sacc = (k == cc) ? 1.f : 0.f;
-      if (i < E) {
+      for (int k = 0; k < 32; ++k) {
+        const int i = base + k;
+        float sacc = (k == cc) ? 1.f : 0.f;
+        if (i < E) {
 #pragma unroll
-        for (int m2 = 0; m2 < k; ++m2) sacc = fmaf(-x[m2], Lp[tri(i, base + m2)], sacc);
-        x[k] = (k >= cc) ? sacc / Lp[tri(i, i)] : 0.f;
-      } else {
-        x[k] = 0.f;
+          for (int m2 = 0; m2 < k; ++m2) sacc = fmaf(-x[m2], Lp[tri(i, base + m2)], sacc);
+          x[k] = (k >= cc) ? sacc / Lp[tri(i, i)] : 0.f;
+        } else {
+          x[k] = 0.f;
+        }
+        __builtin_amdgcn_sched_barrier(0);
       }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    __builtin_amdgcn_wave_barrier();
-    if (lane < 32) {
+      __builtin_amdgcn_wave_barrier();
 #pragma unroll
       for (int k = 0; k < 32; ++k)
         if (k >= cc && base + k < E && base + cc < E) Lp[tri(base + k, base + cc)] = x[k];
