@@ -70,7 +70,20 @@ def cpu_baseline(params, cfg, inst_dict, kind, budget_s=15.0):
     tn = run(n_it)
     per_it = tn / n_it
     full = int(cfg["converge"]["max_iter"])
+    torch.set_num_threads(1)                 # BASELINE.md section 4 also asks for the single-thread figure
+    run(1)
+    per_it_1 = run(2) / 2
+    torch.set_num_threads(threads)
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
     return {"value": 1.0 / (per_it * full), "unit": "instances/s", "cores": threads, "kind": "port",
+            "host": f"{model}, {ncpu} logical CPUs", "single_thread_value": 1.0 / (per_it_1 * full),
             "sample": f"1 instance x {n_it} LM iterations of the same workload on {threads} host threads "
                       f"({per_it * 1e3:.1f} ms/iteration), extrapolated to {full} iterations; oracle in "
                       "reference-faithful mode (dense (n,E,E) Hessian build + torch.inverse)"}
