@@ -41,12 +41,15 @@ def cpu_baseline(params, cfg, inst_dict, kind, budget_s=15.0):
     pw = torch.from_numpy(inst_dict["points_w"])
     rd = {k: [torch.from_numpy(a) for a in v] for k, v in inst_dict["render"].items()}
 
+    split = {}
+
     def run(n_it):
         c = copy.deepcopy(cfg)
         c["converge"]["max_iter"] = n_it
+        split.clear()
         t = time.perf_counter()
         if kind == "joint":
-            O.shape_pose_joint_opt(dec, c, z0, T0, rd, pw, inst_dict["cube_radius"], faithful=True)
+            O.shape_pose_joint_opt(dec, c, z0, T0, rd, pw, inst_dict["cube_radius"], faithful=True, timings=split)
         else:
             O.shape_opt_deepsdf(dec, c, z0, T0, pw, faithful=True)
         return time.perf_counter() - t
@@ -70,6 +73,7 @@ def cpu_baseline(params, cfg, inst_dict, kind, budget_s=15.0):
     tn = run(n_it)
     per_it = tn / n_it
     full = int(cfg["converge"]["max_iter"])
+    split_ms = {k: round(v / n_it * 1e3, 2) for k, v in split.items()}      # render / sdf / solve per iteration
     torch.set_num_threads(1)                 # BASELINE.md section 4 also asks for the single-thread figure
     run(1)
     per_it_1 = run(2) / 2
@@ -84,6 +88,7 @@ def cpu_baseline(params, cfg, inst_dict, kind, budget_s=15.0):
         pass
     return {"value": 1.0 / (per_it * full), "unit": "instances/s", "cores": threads, "kind": "port",
             "host": f"{model}, {ncpu} logical CPUs", "single_thread_value": 1.0 / (per_it_1 * full),
+            "ms_per_iteration_split": split_ms,
             "sample": f"1 instance x {n_it} LM iterations of the same workload on {threads} host threads "
                       f"({per_it * 1e3:.1f} ms/iteration), extrapolated to {full} iterations; oracle in "
                       "reference-faithful mode (dense (n,E,E) Hessian build + torch.inverse)"}

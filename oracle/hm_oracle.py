@@ -365,7 +365,7 @@ def render_term(dec, latent, T_ow, render_data, frame_ind, cube_radius, cur_scal
 
 def shape_pose_joint_opt(dec: FoldedDecoder, opt_cfg, latent, T_ow, render_data, points_w, cube_radius,
                          pose_known=False, faithful=False, trace: Optional[list] = None,
-                         solve64=False):
+                         solve64=False, timings: Optional[dict] = None):
     """Optimizer.shape_pose_joint_opt (optimizer.py:28-302).  Returns (latent, T_ow, iter_count).
     `latent` is NOT mutated (the reference mutates in place, :248; its callers pass a clone)."""
     o = opt_cfg
@@ -389,7 +389,13 @@ def shape_pose_joint_opt(dec: FoldedDecoder, opt_cfg, latent, T_ow, render_data,
     F_all = len(render_data["T_wc"])
     frame_ind = np.linspace(0, F_all - 1, min(int(o["render"]["n_frame"]), F_all)).astype(np.int32)  # :77-78
     iter_count = 0
+    import time as _time
+    def _lap(key, t0):                       # optional wall-clock buckets like the reference's get_time stamps (:91-266)
+        if timings is not None:
+            timings[key] = timings.get(key, 0.0) + (_time.perf_counter() - t0)
+        return _time.perf_counter()
     for i in range(max_iter):                                               # :88
+        _t = _time.perf_counter()
         rt = render_term(dec, latent, T_ow, render_data, frame_ind, cube_radius, cur_scale, o, scale_on)
         if rt is None:                                                      # :139-141
             break
@@ -398,11 +404,13 @@ def shape_pose_joint_opt(dec: FoldedDecoder, opt_cfg, latent, T_ow, render_data,
         rho_d = huber(res_d, t_depth)[1] if i >= robust_iter else torch.ones_like(res_d)   # :145-149
         H_d, b_d = _normal_eq(J_d, res_d, rho_d, w_depth, V, faithful)                     # :152-153
         H_m, b_m = _normal_eq(J_m, res_m, torch.ones_like(res_m), w_mask, V, faithful)     # :158-159
+        _t = _lap("render", _t)
         pts_o = (points_w[..., None, :] * T_ow[:3, :3]).sum(-1) + T_ow[:3, 3]              # :168
         r_s, Jp, Jc = compute_sdf_loss(dec, latent, pts_o, scale_on)                       # :170
         J_s = torch.cat([Jp, Jc], dim=1)
         rho_s = huber(r_s, t_recon)[1] if i >= robust_iter else torch.ones_like(r_s)       # :183-187
         H_s, b_s = _normal_eq(J_s, r_s, rho_s, w_recon, r_s.shape[0], faithful)            # :189-190
+        _t = _lap("sdf", _t)
         H = torch.zeros(E, E, dtype=dt)
         H += H_d; H += H_m; H += H_s                                                       # :210-213
         H[P:, P:] += w_code * torch.eye(L, dtype=dt)                                       # :200-201
@@ -434,6 +442,7 @@ def shape_pose_joint_opt(dec: FoldedDecoder, opt_cfg, latent, T_ow, render_data,
         d_tran = torch.linalg.vector_norm(dT[:3, 3]) * cur_scale                           # :252
         d_rot = torch.abs(torch.acos((torch.trace(dT[:3, :3] * cur_scale) - 1) / 2)) * 180.0 / math.pi  # :253
         iter_count = i + 1                                                                 # :273
+        _t = _lap("solve", _t)
         if bool(torch.max(torch.abs(b)) < eps_g) and i > 1:                                # :276
             break
         if bool(torch.max(torch.abs(dc / (latent + 1e-12))) < eps_c) and i > 1:            # :280
