@@ -1,0 +1,35 @@
+"""bench.py prints ONE JSON line with the fields the driver parses (metric / value / unit / n_gpus / steps / warmup /
+ms_per_step / higher_is_better / scaling / vs_baseline / dtype / data / config + roofline + cpu_baseline).  A small
+job (4 fruits, L = 32, 5 iterations) keeps this test fast; the numbers themselves are not asserted."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_json_contract():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+                          "--batch", "4", "--latent", "32", "--iters", "5"], capture_output=True, text=True,
+                         timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k, t in (("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int),
+                 ("ms_per_step", float), ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str),
+                 ("config", dict), ("roofline", dict), ("cpu_baseline", dict)):
+        assert k in d and isinstance(d[k], t), k
+    assert "vs_baseline" in d and d["vs_baseline"] is None            # BASELINE.md publishes no number for this metric
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["higher_is_better"] is True
+    assert d["scaling"] == "weak" and d["data"] == "synthetic" and d["value"] > 0 and "workload" in d["config"]
+    r = d["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s") and r["peak"] > 0 and r["achieved"] > 0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and "traffic" in r
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] and c["sample"]
+    assert abs(d["value"] - 4 * 2 / (d["ms_per_step"] * 2 * 1e-3)) < 0.02 * d["value"]     # value = units / time
