@@ -2,13 +2,19 @@
 """Benchmark of the hot path: fruit instances per second for the FULL optimisation (BASELINE.json metric).
 
 One "step" = one complete Levenberg-Marquardt optimisation (200 forced iterations, latent + Sim(3) pose) of a batch
-of 64 synthetic peppers per GPU (BASELINE.json configs[1]; SURVEY.md 8d "C2").  Inputs are resident in HBM when the
-timed region starts; the timed region covers every kernel of the loop plus, for N > 1, the single RCCL gather of the
-result records.  Prints ONE JSON line (rank 0) with the `roofline` and `cpu_baseline` objects.
+of synthetic peppers (BASELINE.json configs[1]; SURVEY.md 8d "C2").  Inputs are resident in HBM when the timed region
+starts; the timed region covers every kernel of the loop plus, for N > 1, the single RCCL gather of the result records.
+Prints ONE JSON line (rank 0) with the `roofline` and `cpu_baseline` objects.
 
-    python bench.py                       # 1 GPU, defaults
+    python bench.py                       # 1 GPU, 64 peppers (weak scaling: 64 per GPU)
+    python bench.py --total 4096          # strong scaling (configs[3]): 4096 instances sharded over the GPUs, each rank
+                                          # running its shard in chunks of --batch (default 256 in this mode)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
+
+`--stub-cpu` (tests only, tests/test_distributed_gloo.py) runs the SAME rank logic -- argument check, shard plan,
+chunk loop, record gather, MAX all-reduce of the time, JSON assembly -- on the gloo backend with the GPU optimisation
+replaced by a deterministic stand-in; it measures nothing and says so in the line it prints.
 """
 import argparse
 import ctypes
@@ -28,11 +34,37 @@ FLOP_FWD_BWD = 7342080        # forward + input-gradient backward
 PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
 PEAK_F16_MFMA_TFLOPS = 2500.0 # same table: "Peak BF16/FP16 MFMA ~2.5 PF dense"
 
+PRECISIONS = {
+    # name: (peak the dominant kernel is priced against, kernel name, note)
+    "f32": (PEAK_F32_MFMA_TFLOPS, "k_decoder<1,0>", "f32 = exact fp32 MFMA (v_mfma_f32_32x32x2_f32)"),
+    "f16x3": (PEAK_F16_MFMA_TFLOPS, "k_decoder_h<1,0,0>",
+              "f16x3 = fp16 MFMA on hi/lo split operands (three passes per product), fp32 accumulate, results "
+              "fp32-class: ~2^-22 relative per product"),
+    "f16x3f_f16b": (PEAK_F16_MFMA_TFLOPS, "k_decoder_h<1,0,1>",
+                    "mixed: forward (residuals) as f16x3, input-gradient backward (Jacobians) as ONE fp16 MFMA pass "
+                    "on the hi parts (J ~1e-3 relative); not fp32-class, never the default line"),
+}
+TRAFFIC_FILE = os.path.join("profiles", "r02_traffic.json")
 
-def cpu_baseline(params, cfg, inst_dict, kind, budget_s=15.0):
+
+def plan_shard(rank, world, per_gpu, total, chunk):
+    """(ids, chunks, n_total): the global instance ids this rank owns and its chunk bounds (in local indices).
+    Weak scaling (total == 0): rank r owns [r * per_gpu, (r + 1) * per_gpu) as ONE chunk.  Strong scaling: the
+    contiguous block partition of `distributed.shard_bounds` over `total` instances, cut into chunks of `chunk`."""
+    from hortimapping_amd import distributed as D
+    if total <= 0:
+        ids = list(range(rank * per_gpu, (rank + 1) * per_gpu))
+        return ids, [(0, per_gpu)], per_gpu * world
+    lo, hi = D.shard_bounds(total, rank, world)
+    ids = list(range(lo, hi))
+    n = hi - lo
+    return ids, [(c, min(n, c + chunk)) for c in range(0, n, chunk)], total
+
+
+def cpu_baseline(params, cfg, inst_dict, kind, budget_s=25.0):
     """The oracle (CPU restatement, reference-faithful op structure: per-query Jacobian, dense (n,E,E) outer-product
-    Hessian, torch.inverse) timed on this box's host cores on a bounded sample: ONE instance, a few iterations of the
-    same workload, extrapolated to the 200-iteration optimisation."""
+    Hessian, torch.inverse) timed on this box's host cores on a bounded sample: ONE instance, as many LM iterations of
+    the same workload as fit ~25 s (up to the full 200), scaled to the 200-iteration optimisation."""
     from oracle import hm_oracle as O
     import copy
     dec = O.fold_decoder(params)
@@ -69,10 +101,10 @@ def cpu_baseline(params, cfg, inst_dict, kind, budget_s=15.0):
     torch.set_num_threads(threads)
     t2 = run(2)
     per_it = t2 / 2
-    n_it = int(max(3, min(60, budget_s / max(per_it, 1e-3))))
+    full = int(cfg["converge"]["max_iter"])
+    n_it = int(max(3, min(full, budget_s / max(per_it, 1e-3))))
     tn = run(n_it)
     per_it = tn / n_it
-    full = int(cfg["converge"]["max_iter"])
     split_ms = {k: round(v / n_it * 1e3, 2) for k, v in split.items()}      # render / sdf / solve per iteration
     torch.set_num_threads(1)                 # BASELINE.md section 4 also asks for the single-thread figure
     run(1)
@@ -86,98 +118,132 @@ def cpu_baseline(params, cfg, inst_dict, kind, budget_s=15.0):
                 break
     except OSError:
         pass
-    return {"value": 1.0 / (per_it * full), "unit": "instances/s", "cores": threads, "kind": "port",
+    return {"value": 1.0 / (per_it * full), "unit": "instances/s", "cores": threads, "cores_of": ncpu,
+            "cores_note": f"{threads} of {ncpu} logical CPUs (fastest of the thread counts tried)", "kind": "port",
             "host": f"{model}, {ncpu} logical CPUs", "single_thread_value": 1.0 / (per_it_1 * full),
             "ms_per_iteration_split": split_ms,
-            "sample": f"1 instance x {n_it} LM iterations of the same workload on {threads} host threads "
-                      f"({per_it * 1e3:.1f} ms/iteration), extrapolated to {full} iterations; oracle in "
+            "sample": f"1 instance x {n_it} of {full} LM iterations of the same workload on {threads} host threads "
+                      f"({per_it * 1e3:.1f} ms/iteration), scaled to {full} iterations; oracle in "
                       "reference-faithful mode (dense (n,E,E) Hessian build + torch.inverse)"}
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="c2_joint", choices=["c2_joint", "c2_sdf"])
-    ap.add_argument("--batch", type=int, default=64, help="instances per GPU per step")
+    ap.add_argument("--batch", type=int, default=0,
+                    help="instances per GPU per step (weak scaling, default 64) or chunk size (--total, default 256)")
+    ap.add_argument("--total", type=int, default=0,
+                    help="strong scaling: this many instances in total, sharded over the GPUs (configs[3]: 4096)")
     ap.add_argument("--latent", type=int, default=256)
     ap.add_argument("--iters", type=int, default=200)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--streams", type=int, default=1, help="independent sub-batches on separate HIP streams")
-    ap.add_argument("--no-exact", action="store_true", help="skip the extra exact-fp32 reference step")
-    ap.add_argument("--precision", default=os.environ.get("HM_PRECISION", "f16x3"), choices=["f32", "f16x3"],
-                    help="decoder GEMM arithmetic: exact fp32 MFMA or fp16 MFMA with hi/lo split operands")
-    args = ap.parse_args()
+    ap.add_argument("--no-exact", action="store_true", help="skip the extra exact-fp32 / mixed-precision steps")
+    ap.add_argument("--precision", default=os.environ.get("HM_PRECISION", "f16x3"), choices=sorted(PRECISIONS),
+                    help="decoder GEMM arithmetic of the primary line")
+    ap.add_argument("--stub-cpu", action="store_true", help=argparse.SUPPRESS)
+    return ap.parse_args(argv)
 
+
+def main(argv=None):
+    args = parse_args(argv)
     from hortimapping_amd import distributed as D
-    rank, local_rank, world = D.init_from_env()
-    if args.gpus != world and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-
-    from hortimapping_amd import _lib, synthetic as S, workloads as W, optimizer as HO
-    from hortimapping_amd.decoder import DecoderWeights
     import torch.distributed as dist
+    stub = args.stub_cpu
+    rank, local_rank, world = D.init_from_env(backend="gloo" if stub else None)
+    if args.gpus != world:
+        if world > 1 or args.gpus > 1:
+            raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run "
+                             f"--nproc-per-node {args.gpus}")
+    if not stub:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+        torch.cuda.set_device(local_rank)
+    dev = torch.device("cpu") if stub else torch.device("cuda", local_rank)
 
-    L, B = args.latent, args.batch
+    L = args.latent
     kind = "joint" if args.workload == "c2_joint" else "sdf"
-    params = S.make_synthetic_decoder(L, seed=2, r0=0.04, aniso=(1.0, 0.75, 1.3))
-    dec = DecoderWeights.from_params(params)
-    cfg = W.c2_opt_cfg(max_iter=args.iters, n_sample_on_ray=16, n_frame=1)
-    hcfg = HO.opt_cfg_from_dict(cfg)
-
-    ids = list(range(rank * B, rank * B + B))           # weak scaling: every GPU owns its own 64 instances
-    dicts = W.make_c2_instances(params, dec, ids, kind=kind, device=dev)
-    insts = [W.to_instance(d) for d in dicts]
+    strong = args.total > 0
+    per_gpu = args.batch or 64
+    chunk = args.batch or 256
+    ids, chunks, n_total = plan_shard(rank, world, per_gpu, args.total, chunk)
+    n_local = len(ids)
+    DISTINCT = 64                              # distinct synthetic peppers; larger jobs replicate them cyclically
     shape_only = kind == "sdf"
-    # The batch is optimised as `--streams` independent sub-batches on separate HIP streams: while one sub-batch is
-    # in its latency-bound tail (normal equations, Cholesky solve, ray scan) the other keeps the matrix cores busy.
-    # Instances are independent, so this changes nothing but the overlap (results are bitwise those of one batch).
-    n_sub = max(1, min(args.streams, B))
-    bounds = [(i * B // n_sub, (i + 1) * B // n_sub) for i in range(n_sub)]
-    pbs = [HO.PackedBatch(insts[lo:hi], L, 1, dev, joint=not shape_only) for lo, hi in bounds]
-    wss = [HO.Workspace(dec, hi - lo, pb_.points_stride, pb_.F, pb_.R, 0 if shape_only else hcfg.n_sample_on_ray)
-           for (lo, hi), pb_ in zip(bounds, pbs)]
-    streams = [torch.cuda.Stream(device=dev) for _ in range(n_sub)]
-    lat0s, T0s = [p_.latent.clone() for p_ in pbs], [p_.T_ow.clone() for p_ in pbs]
-    pb, ws = pbs[0], wss[0]
-    lib = _lib.lib()
-    lib.hm_workspace_profile.argtypes = [ctypes.c_void_p, ctypes.c_int]
-    lib.hm_workspace_profile_read.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double),
-                                              ctypes.POINTER(ctypes.c_longlong)]
-    n_total = B * world
+
+    if stub:
+        params = cfg = dicts = None
+        state = {"precision": args.precision}
+
+        def set_precision(p):
+            state["precision"] = p
+
+        def run_chunk(lo, hi):               # deterministic stand-in for hm_optimize_batch on instances ids[lo:hi]
+            g = torch.tensor(ids[lo:hi], dtype=torch.float32)
+            lat = g[:, None] * 1000 + torch.arange(L, dtype=torch.float32)[None]
+            T = g[:, None].repeat(1, 16) + 0.5
+            return D.pack_records(lat, T, torch.full((hi - lo,), args.iters), torch.full((hi - lo,), 8))
+        profile_read = lambda: (0.0, 0)
+        profile_on = lambda on: None
+        n_s = 0
+    else:
+        from hortimapping_amd import _lib, synthetic as S, workloads as W, optimizer as HO
+        from hortimapping_amd.decoder import DecoderWeights
+        params = S.make_synthetic_decoder(L, seed=2, r0=0.04, aniso=(1.0, 0.75, 1.3))
+        dec = DecoderWeights.from_params(params)
+        cfg = W.c2_opt_cfg(max_iter=args.iters, n_sample_on_ray=16, n_frame=1)
+        hcfg = HO.opt_cfg_from_dict(cfg)
+        need = sorted({i % DISTINCT for i in ids}) if strong else ids
+        made = dict(zip(need, W.make_c2_instances(params, dec, need, kind=kind, device=dev)))
+        dicts = [made[i % DISTINCT if strong else i] for i in ids]
+        insts = [W.to_instance(d) for d in dicts]
+        pbs = [HO.PackedBatch(insts[lo:hi], L, 1, dev, joint=not shape_only) for lo, hi in chunks]
+        cmax = max(hi - lo for lo, hi in chunks)
+        ws = HO.Workspace(dec, cmax, max(p.points_stride for p in pbs), pbs[0].F, pbs[0].R,
+                          0 if shape_only else hcfg.n_sample_on_ray)          # ONE workspace, reused by every chunk
+        init = [(p.latent.clone(), p.T_ow.clone()) for p in pbs]
+        lib = _lib.lib()
+        lib.hm_workspace_profile.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        lib.hm_workspace_profile_read.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double),
+                                                  ctypes.POINTER(ctypes.c_longlong)]
+        set_precision = dec.set_precision
+
+        def run_chunk_idx(k):
+            p_ = pbs[k]
+            p_.latent.copy_(init[k][0])
+            p_.T_ow.copy_(init[k][1])
+            HO.run_packed(ws, hcfg, p_, 1 if shape_only else 0)
+            return D.pack_records(p_.latent, p_.T_ow.reshape(p_.B, 16), p_.iter_count, p_.status)
+
+        def profile_on(on):
+            lib.hm_workspace_profile(ws.handle, 1 if on else 0)
+
+        def profile_read():
+            ms_tot, n_launch = ctypes.c_double(0), ctypes.c_longlong(0)
+            lib.hm_workspace_profile_read(ws.handle, ctypes.byref(ms_tot), ctypes.byref(n_launch))
+            return ms_tot.value, int(n_launch.value)
+        n_s = int(pbs[0].n_points.sum().item())           # queries of one profiled launch (first chunk's size class)
 
     def step():
-        cur = torch.cuda.current_stream(dev)
-        recs = []
-        for p_, w_, s_, l0, t0_ in zip(pbs, wss, streams, lat0s, T0s):
-            s_.wait_stream(cur)
-            with torch.cuda.stream(s_):
-                p_.latent.copy_(l0)
-                p_.T_ow.copy_(t0_)
-                HO.run_packed(w_, hcfg, p_, 1 if shape_only else 0)
-                recs.append(D.pack_records(p_.latent, p_.T_ow.reshape(p_.B, 16), p_.iter_count, p_.status))
-        for s_ in streams:
-            cur.wait_stream(s_)
-        rec = torch.cat(recs, dim=0)
-        return D.gather_records(rec, n_total)           # the single RCCL all-gather over xGMI (no-op for N = 1)
+        recs = [run_chunk(lo, hi) if stub else run_chunk_idx(k) for k, (lo, hi) in enumerate(chunks)]
+        rec = torch.cat(recs, dim=0) if recs else torch.zeros(0, L + 18, device=dev)
+        return D.gather_records(rec, n_total)     # the single RCCL all-gather over xGMI (no-op for N = 1)
 
     def fence():
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        if not stub:
+            torch.cuda.synchronize()
 
     def measure(precision, steps, warmup):
         """W untimed steps, then exactly K timed steps bracketed by barrier + synchronize; max over ranks."""
-        dec.set_precision(precision)
+        set_precision(precision)
         for _ in range(warmup):
             step()
         fence()
-        lib.hm_workspace_profile(ws.handle, 1)
+        profile_on(True)
         t0 = time.perf_counter()
         for _ in range(steps):
             allrec = step()
@@ -187,79 +253,95 @@ def main():
             tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             dt = float(tmax.item())
-        ms_tot, n_launch = ctypes.c_double(0), ctypes.c_longlong(0)
-        lib.hm_workspace_profile_read(ws.handle, ctypes.byref(ms_tot), ctypes.byref(n_launch))
-        lib.hm_workspace_profile(ws.handle, 0)
-        return dt, ms_tot.value, int(n_launch.value), allrec
+        ms_tot, n_launch = profile_read()
+        profile_on(False)
+        return dt, ms_tot, n_launch, allrec
 
-    n_s = int(pb.n_points.sum().item())                   # profiled launches: sub-batch 0
-    flops_per_launch = n_s * FLOP_FWD_BWD                 # SDF-term K1 launch: all B instances' surface points
+    # the profiled launches are the SDF-term K1 launches of every chunk; price them per query
+    queries_per_launch = n_s if not strong else None
 
     def roofline(precision, ms_tot, n_launch):
+        peak, kname, _ = PRECISIONS[precision]
         avg_ms = ms_tot / max(1, n_launch)
-        achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12
-        peak = PEAK_F16_MFMA_TFLOPS if precision == "f16x3" else PEAK_F32_MFMA_TFLOPS
-        kname = "k_decoder_h<1,0>" if precision == "f16x3" else "k_decoder<1,0>"
-        traffic = None        # HBM/fabric bytes per launch from the committed PMC passes (same workload only)
-        tj = os.path.join(ROOT, "profiles", "r01_traffic.json")
-        if kind == "joint" and B == 64 and L == 256 and os.path.exists(tj):
+        # all chunks of this rank have the same size except possibly the last: use the mean queries per launch
+        q = (sum(int(p.n_points.sum().item()) for p in pbs) / len(pbs)) if queries_per_launch is None else queries_per_launch
+        flops = q * FLOP_FWD_BWD
+        achieved = flops / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+        traffic, tsrc = None, None    # HBM/fabric bytes per launch: from committed PMC passes of the same workload
+        tj = os.path.join(ROOT, TRAFFIC_FILE)
+        if kind == "joint" and not strong and per_gpu == 64 and L == 256 and os.path.exists(tj):
             traffic = json.load(open(tj)).get(precision, {}).get("bytes_per_launch")
+            if traffic is not None:
+                tsrc = f"{TRAFFIC_FILE} (rocprofv3 PMC passes of the same workload, committed; NOT measured in this run)"
         r = {"bound": "mfma", "kernel": kname + " (SDF-term decoder forward + input-gradient backward)",
              "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
-             "traffic": traffic, "launches": n_launch, "avg_launch_ms": round(avg_ms, 4),
-             "algorithmic_flop_per_launch": flops_per_launch}
+             "traffic": traffic, "traffic_source": tsrc, "launches": n_launch, "avg_launch_ms": round(avg_ms, 4),
+             "algorithmic_flop_per_launch": int(flops)}
         if precision == "f16x3":
             r["note"] = ("achieved counts ALGORITHMIC flop (dense fp32 decoder); the split-operand kernel issues 3 fp16 "
-                         "MFMA passes per product, so matrix-pipe utilisation is about 3 x 0.93 x frac")
+                         "MFMA passes per product, so its ceiling is 1/3 of the fp16 peak")
+        elif precision == "f16x3f_f16b":
+            r["note"] = "3 MFMA passes per forward product, 1 per backward product: ceiling 1/2 of the fp16 peak"
         return r
 
     dt, ms_tot, n_launch, allrec = measure(args.precision, args.steps, args.warmup)
 
     if rank == 0:
         lat, T, it, st = D.unpack_records(allrec.cpu(), L)
+        assert lat.shape[0] == n_total, (lat.shape, n_total)
         assert torch.isfinite(lat).all() and torch.isfinite(T).all(), "non-finite result"
         assert int(it.min()) == args.iters, f"iter_count {it.min()}..{it.max()} != {args.iters}"
+        if stub:                                  # instance order survived the shard / chunk / gather path
+            assert torch.equal(lat[:, 0], torch.arange(n_total, dtype=torch.float32) * 1000)
     value = n_total * args.steps / dt
-    out = {
-        "metric": "fruit-instances/sec full optimisation (200 iters, 2048 pts)",
-        "value": round(value, 3), "unit": "instances/s", "n_gpus": world, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None,
-        "dtype": args.precision,
-        "dtype_note": ("f16x3 = fp16 MFMA on hi/lo split operands (three passes per product), fp32 accumulate, results "
-                       "fp32-class: ~2^-22 relative, same error vs the fp64 oracle as exact fp32"
-                       if args.precision == "f16x3" else "f32 = exact fp32 MFMA (v_mfma_f32_32x32x2_f32)"),
-        "data": "synthetic",
-        "config": {
-            "workload": ("c2_joint: 64 synthetic peppers per GPU, 256-dim latent, 8x512 DeepSDF decoder, "
-                         "joint latent + Sim(3) pose LM, 1024 surface pts + 1 frame x 64 rays x 16 samples "
-                         "(2048 decoder pts/iteration), 200 forced iterations" if kind == "joint" else
-                         "c2_sdf: 64 synthetic peppers per GPU, 256-dim latent, 8x512 DeepSDF decoder, shape-only "
-                         "LM (shape_opt_deepsdf), 2048 surface pts, 200 forced iterations"),
-            "instances_per_gpu": B, "latent_dim": L, "iterations": args.iters, "precision": args.precision,
-            "streams": n_sub,
-            "parallelism": f"instances sharded over {world} GPU(s), one RCCL all-gather of results per step",
-        },
-        "roofline": roofline(args.precision, ms_tot, n_launch),
-    }
-    if args.precision != "f32" and not args.no_exact and world == 1:
-        # the same job in exact fp32 arithmetic (v_mfma_f32_32x32x2_f32), one timed step, for reference
-        dt2, ms2, nl2, allrec2 = measure("f32", 1, 1)
-        if rank == 0:
-            l2, T2, _, _ = D.unpack_records(allrec2.cpu(), L)
-            out["exact_f32"] = {"value": round(n_total / dt2, 3), "unit": "instances/s", "steps": 1,
-                                "ms_per_step": round(dt2 * 1e3, 3), "roofline": roofline("f32", ms2, nl2),
-                                "max_abs_latent_diff_vs_primary": float((l2 - lat).abs().max()),
-                                "max_abs_T_diff_vs_primary": float((T2 - T).abs().max()),
-                                "diff_note": "free-pose 200-iteration trajectories amplify rounding noise (two fp32 "
-                                             "evaluations of the reference itself differ as much, DESIGN.md section 2)"}
+    out = None
     if rank == 0:
-        if not args.no_cpu_baseline and world == 1:     # reported at N = 1 only; other ranks would idle in the barrier
+        joint_txt = ("256-dim latent, 8x512 DeepSDF decoder, joint latent + Sim(3) pose LM, 1024 surface pts + 1 frame "
+                     "x 64 rays x 16 samples (2048 decoder pts/iteration), %d forced iterations" % args.iters)
+        sdf_txt = ("256-dim latent, 8x512 DeepSDF decoder, shape-only LM (shape_opt_deepsdf), 2048 surface pts, "
+                   "%d forced iterations" % args.iters)
+        head = (f"{args.workload}: {n_total} synthetic peppers in total ({DISTINCT} distinct, replicated), sharded over "
+                f"the GPUs in chunks of {chunk}" if strong else f"{args.workload}: {per_gpu} synthetic peppers per GPU")
+        out = {
+            "metric": "fruit-instances/sec full optimisation (200 iters, 2048 pts)",
+            "value": round(value, 3), "unit": "instances/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "strong" if strong else "weak", "vs_baseline": None,
+            "dtype": args.precision, "dtype_note": PRECISIONS[args.precision][2],
+            "data": "synthetic",
+            "config": {
+                "workload": head + ", " + (joint_txt if kind == "joint" else sdf_txt),
+                "instances_total": n_total, "instances_per_gpu": n_local, "chunk": chunk if strong else per_gpu,
+                "latent_dim": L, "iterations": args.iters, "precision": args.precision,
+                "parallelism": f"instances sharded over {world} GPU(s), one RCCL all-gather of results per step",
+            },
+        }
+        if stub:
+            out["stub"] = "rank logic only (gloo, CPU stand-in for the GPU optimisation): NOT a measurement"
+        else:
+            out["roofline"] = roofline(args.precision, ms_tot, n_launch)
+    if not stub and not args.no_exact and world == 1 and not strong:
+        # the same job in the other decoder arithmetics, one timed step each, for reference next to the primary line
+        for other, key in (("f32", "exact_f32"), ("f16x3f_f16b", "mixed_f16x3f_f16b")):
+            if other == args.precision:
+                continue
+            dt2, ms2, nl2, allrec2 = measure(other, 1, 1)
+            l2, T2, _, _ = D.unpack_records(allrec2.cpu(), L)
+            out[key] = {"value": round(n_total / dt2, 3), "unit": "instances/s", "steps": 1, "dtype": other,
+                        "dtype_note": PRECISIONS[other][2], "ms_per_step": round(dt2 * 1e3, 3),
+                        "roofline": roofline(other, ms2, nl2),
+                        "max_abs_latent_diff_vs_primary": float((l2 - lat).abs().max()),
+                        "max_abs_T_diff_vs_primary": float((T2 - T).abs().max()),
+                        "diff_note": "free-pose 200-iteration trajectories amplify rounding noise; per-instance parity of "
+                                     "every arithmetic vs the CPU oracle: profiles/r02_parity_fullsize_*.txt"}
+    if rank == 0:
+        if not stub and not args.no_cpu_baseline and world == 1:   # N = 1 only; other ranks would idle in the barrier
             out["cpu_baseline"] = cpu_baseline(params, cfg, dicts[0], kind)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    return out
 
 
 if __name__ == "__main__":

@@ -38,10 +38,6 @@ struct DecodeArgsH {
   long long* trace;    // optional [NSTAGE][4] shader-clock stamps of block 0 / wave 0 (perf analysis), or nullptr
 };
 
-#ifndef HM_DIAG
-#define HM_DIAG 0  // 1..3: timing-only experiments (results are garbage), see scripts/diag_k1h.sh
-#endif
-
 constexpr float LO_SCALE = 2048.f;          // 2^11
 constexpr float LO_UNSCALE = 1.f / 2048.f;
 
@@ -65,52 +61,15 @@ __device__ __forceinline__ void split_store(f16x4* xh4, f16x4* xl4, int idx, con
   xl4[idx] = l;
 }
 
-// One K-step (16 k) of the split product for the two row blocks of this wave: 12 MFMAs.
-template <bool U0, bool U1>
-__device__ __forceinline__ void mfma_step_h(f32x16 (&acc)[2][2], const f16x8& a0h, const f16x8& a0l,
-                                            const f16x8& a1h, const f16x8& a1l, const f16x8& b0h,
-                                            const f16x8& b1h, const f16x8& b0l, const f16x8& b1l) {
-  const _Float16 cs = (_Float16)LO_UNSCALE;
-#if HM_DIAG == 1  // loads only: consume every operand with one VALU op each, no matrix work
-  acc[0][0][0] += (float)(a0h[0] + a0l[0] + a1h[0] + a1l[0]) + (float)(b0h[0] + b1h[0] + b0l[0] + b1l[0]);
-  return;
-#endif
-  if (U0) {
-    const f16x8 a0c = a0h * cs;
-    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, b0h, acc[0][0], 0, 0, 0);
-    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, b1h, acc[0][1], 0, 0, 0);
-    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0c, b0l, acc[0][0], 0, 0, 0);
-    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0c, b1l, acc[0][1], 0, 0, 0);
-    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0l, b0h, acc[0][0], 0, 0, 0);
-    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0l, b1h, acc[0][1], 0, 0, 0);
-  }
-  if (U1) {
-    const f16x8 a1c = a1h * cs;
-    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, b0h, acc[1][0], 0, 0, 0);
-    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, b1h, acc[1][1], 0, 0, 0);
-    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1c, b0l, acc[1][0], 0, 0, 0);
-    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1c, b1l, acc[1][1], 0, 0, 0);
-    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1l, b0h, acc[1][0], 0, 0, 0);
-    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1l, b1h, acc[1][1], 0, 0, 0);
-  }
-}
-
 // K loop.  Weights (A, from L2) are fetched TWO K-steps ahead into a ring of three statically named register sets,
 // activations (B, from LDS) one step ahead into a ring of two; the loop is unrolled by six so every set has a fixed
 // name (no register rotation => hipcc emits counted waits instead of draining vmcnt/lgkmcnt each step), and
 // sched_barriers pin each prefetch between the MFMAs it overlaps (hipcc otherwise sinks loads to their first use).
-// HM_DIAG = 1 / 2 / 3 build timing-only variants (loads only / L1-resident weights / no weight fetches) that were
-// used to attribute the loop time (scripts/diag_k1h.sh); results are garbage in those builds.
 struct ASet { f16x8 h0, l0, h1, l1; };
 struct BSet { f16x8 h0, h1, l0, l1; };
 
 template <bool U0, bool U1>
 __device__ __forceinline__ void load_a(ASet& a, const f16x8* __restrict__ wp0, const f16x8* __restrict__ wp1, int k) {
-#if HM_DIAG == 2  // every weight fetch hits the same lines (L1-resident): isolates the L2 stream
-  k = 0;
-#elif HM_DIAG == 3  // no weight fetches after the first: matrix pipe + LDS only
-  if (k > 1) return;
-#endif
   if (U0) { a.h0 = wp0[k * 128]; a.l0 = wp0[k * 128 + 64]; }
   if (U1) { a.h1 = wp1[k * 128]; a.l1 = wp1[k * 128 + 64]; }
 }
@@ -131,18 +90,11 @@ __device__ __forceinline__ void step_h(f32x16 (&acc)[2][2], const ASet& a, const
                                        const f16x8* __restrict__ wp0, const f16x8* __restrict__ wp1, int ka,
                                        const f16x8* xh, const f16x8* xl, int kb, int xo) {
   const _Float16 cs = (_Float16)LO_UNSCALE;
-#if HM_DIAG == 2
-  ka = 0;
-#endif
   const f16x8* w0 = wp0 + ka * 128;
   const f16x8* w1 = wp1 + ka * 128;
   const f16x8* ph = xh + kb * 2 * TQ + xo;
   const f16x8* pl = xl + kb * 2 * TQ + xo;
-#if HM_DIAG == 3
-#define HM_LDA(dst, src)
-#else
 #define HM_LDA(dst, src) dst = src
-#endif
 #define HM_LDB(dst, src) dst = src
   if (U0 && U1) {
     const f16x8 a0c = a.h0 * cs;
@@ -192,22 +144,11 @@ __device__ __forceinline__ void gemm_loop_h(f32x16 (&acc)[2][2], const f16x8* __
   load_a<U0, U1>(a0, wp0, wp1, 0);
   load_a<U0, U1>(a1, wp0, wp1, last < 1 ? last : 1);
   load_b(b0, xh, xl, 0, xo);
-#if HM_DIAG == 1 || defined(HM_BUNCHED)
-#define HM_STEP(AS, BS, ANEXT, BNEXT, I)                                                         \
-  if (HM_COND(I)) {                                                                              \
-    load_a<U0, U1>(ANEXT, wp0, wp1, (ks + (I) + 2 < n_k16) ? ks + (I) + 2 : last);               \
-    load_b(BNEXT, xh, xl, (ks + (I) + 1 < n_k16) ? ks + (I) + 1 : last, xo);                     \
-    __builtin_amdgcn_sched_barrier(0);                                                           \
-    mfma_step_h<U0, U1>(acc, AS.h0, AS.l0, AS.h1, AS.l1, BS.h0, BS.h1, BS.l0, BS.l1);            \
-    __builtin_amdgcn_sched_barrier(0);                                                           \
-  }
-#else
 #define HM_STEP(AS, BS, ANEXT, BNEXT, I)                                                         \
   if (HM_COND(I)) {                                                                              \
     step_h<U0, U1>(acc, AS, BS, ANEXT, BNEXT, wp0, wp1, (ks + (I) + 2 < n_k16) ? ks + (I) + 2 : last, xh, xl, \
                    (ks + (I) + 1 < n_k16) ? ks + (I) + 1 : last, xo);                            \
   }
-#endif
   // full groups of six run branch-free: with a conditional per step hipcc's wait-count pass merges the "step
   // skipped" paths and emits vmcnt(1) where vmcnt(4+) is right, which cuts the two-step prefetch distance to one
   int ks = 0;

@@ -10,6 +10,7 @@
 #define HM_STATUS_INVALID 16      // optimizer.py:139-141 "This submap is not valid"
 #define HM_STATUS_SOLVE_FAILED 32 // non-finite / non-SPD system (the reference would propagate NaN)
 #define HM_STATUS_FRAME_SKIPPED 64 // a frame returned None in some iteration (optimizer.py:130-132), informational
+#define HM_STATUS_LIMIT 128       // instance exceeds a workspace capacity: refused / stopped, never silently truncated
 
 namespace hm {
 

@@ -12,6 +12,7 @@
 // XCD's L2.  Fixed summation order => bitwise reproducible.
 #include "hm_common.h"
 #include "hm_internal.h"
+#include "hm_device_fn.h"
 
 using namespace hm;
 
@@ -25,13 +26,6 @@ struct NormalEqArgs {
   const int* active;
   float* Hext;     // [B][ldJ][ldJ], lower block pairs written
 };
-
-__device__ __forceinline__ float huber_rho(float r, float th) {
-  // w^2 with w = 1 inside the window, sqrt(2 b |r| - b^2)/|r| outside (utils.py:327-340)
-  const float a = fabsf(r);
-  if (th <= 0.f || a <= th) return 1.f;
-  return (2.f * th * a - th * th) / (a * a);
-}
 
 constexpr int CH = 64;        // rows staged per chunk
 constexpr int TW = 64;        // tile width: 2 x 2 blocks of 32 columns per workgroup (one block per wave)

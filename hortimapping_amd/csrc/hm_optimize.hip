@@ -98,6 +98,28 @@ __global__ void k_fill_int(int* p, int n, int v) {
   if (i < n) p[i] = v;
 }
 
+// Per-instance capacity check (device side: the counts live in HBM and the loop never synchronises the host).  An
+// instance that does not fit is switched off before the first iteration and flagged HM_STATUS_LIMIT -- without this,
+// k_transform_points / the decoder would silently truncate its points while K4 walks n_points[b] rows into the next
+// instance's Jacobian buffer.
+__global__ void k_check_limits(int B, int mode, const int* __restrict__ n_points, int n_cap,
+                               const int* __restrict__ n_frames, const int* __restrict__ n_fg,
+                               const int* __restrict__ n_bg, int F_cap, int R_cap, int* __restrict__ active,
+                               int* __restrict__ status) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  bool bad = n_points[b] < 0 || n_points[b] > n_cap;
+  if (mode == 0) {
+    const int nf = n_frames[b];
+    bad = bad || nf < 0 || nf > F_cap;
+    for (int f = 0; f < F_cap && f < nf; ++f) {
+      const int a = n_fg[b * F_cap + f], c = n_bg[b * F_cap + f];
+      bad = bad || a < 0 || c < 0 || a + c > R_cap;
+    }
+  }
+  if (bad) { active[b] = 0; status[b] = HM_STATUS_LIMIT; }
+}
+
 __global__ void k_collect_counts(const RenderCfg cfg, const RenderBuffers rb, int B, int* out) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
@@ -116,6 +138,9 @@ int check_batch(const hm_workspace_s* ws, const hm_batch* bt, int mode) {
   if (bt->d_points_w == nullptr || bt->d_n_points == nullptr || bt->d_latent == nullptr || bt->d_T_ow == nullptr ||
       bt->d_iter_count == nullptr || bt->d_status == nullptr) { hm_set_error("null pointer in batch"); return -1; }
   if (bt->points_stride <= 0) { hm_set_error("points_stride must be positive"); return -1; }
+  if (bt->points_stride > ws->nS_stride) {
+    hm_set_error("points_stride %d exceeds the workspace's point capacity %d (limits.max_points %d)",
+                 bt->points_stride, ws->nS_stride, ws->lim.max_points); return -1; }
   if (mode == 0 && (bt->d_T_wc == nullptr || bt->d_rays == nullptr || bt->d_depth == nullptr || bt->d_n_fg == nullptr ||
                     bt->d_n_bg == nullptr || bt->d_n_frames == nullptr || bt->d_cube_radius == nullptr)) {
     hm_set_error("render inputs missing for joint optimisation"); return -1; }
@@ -230,6 +255,9 @@ extern "C" int hm_optimize_batch(hm_workspace_s* ws, const hm_opt_cfg* cfg, cons
   hipLaunchKernelGGL(k_fill_int, dim3((B + 255) / 256), dim3(256), 0, st, ws->active, B, 1);
   hipLaunchKernelGGL(k_fill_int, dim3((B + 255) / 256), dim3(256), 0, st, bt->d_iter_count, B, 0);
   hipLaunchKernelGGL(k_fill_int, dim3((B + 255) / 256), dim3(256), 0, st, bt->d_status, B, 0);
+  hipLaunchKernelGGL(k_check_limits, dim3((B + 255) / 256), dim3(256), 0, st, B, mode, bt->d_n_points,
+                     bt->points_stride, bt->d_n_frames, bt->d_n_fg, bt->d_n_bg, ws->lim.max_frames, ws->lim.max_rays,
+                     ws->active, bt->d_status);
   HM_CHECK_HIP(hipGetLastError());
 
   RenderCfg rcfg = make_render_cfg(ws, cfg);

@@ -268,7 +268,11 @@ __global__ __launch_bounds__(1024) void k_ray_offsets(const RenderCfg cfg, const
   }
   if (tid == 0) {
     int ng = carry_k;
-    if (ng > rb.nG_stride) ng = rb.nG_stride;   // capacity clamp (reported through hm_workspace limits)
+    if (ng > rb.nG_stride) {     // more Jacobian samples than limits.max_grad_samples: the per-ray sums would be
+      ng = rb.nG_stride;         // partial and the normal equations biased, so report it and let K5 stop the instance
+      if (rb.status != nullptr) rb.status[b] |= HM_STATUS_LIMIT;
+      rb.nflag[b] = 1;
+    }
     rb.nG[b] = ng;
     rb.V[b] = carry_e;
   }

@@ -120,3 +120,31 @@ def init_T_wo(center, rot_y_rad, bbx_size, cfg_opt, object_radius_max_m):
     T[:3, :3] = scale * np.array([[c, 0, s], [0, 1, 0], [-s, 0, c]])
     T[:3, 3] = center
     return T
+
+
+def final_pose_check(T_ow: np.ndarray, outlier_cfg: dict):
+    """`test_wild_completion.py:228-246`: T_wo = inv(T_ow); scale = det(R s)^(1/3); zyx Euler angles of the rotation;
+    an instance is dropped when the scale leaves [scale_min, scale_max] or |pitch| / |roll| exceed rot_max_deg.
+    Returns (T_wo, final_scale, (yaw, pitch, roll) [deg], keep)."""
+    from numpy.linalg import det, inv
+    from scipy.spatial.transform import Rotation
+    T_wo = inv(np.asarray(T_ow))
+    final_scale = det(T_wo[:3, :3]) ** (1 / 3)
+    yaw, pitch, roll = Rotation.from_matrix(T_wo[:3, :3] / final_scale).as_euler("zyx", degrees=True)
+    keep = not (final_scale < outlier_cfg["scale_min"] or final_scale > outlier_cfg["scale_max"]
+                or abs(pitch) > outlier_cfg["rot_max_deg"] or abs(roll) > outlier_cfg["rot_max_deg"])
+    return T_wo, float(final_scale), (float(yaw), float(pitch), float(roll)), bool(keep)
+
+
+def voxel_down_sample(points: np.ndarray, voxel_size: float) -> np.ndarray:
+    """Open3D `PointCloud.voxel_down_sample` (used on the Background submap, test_wild_completion.py:149-150): one
+    point per occupied voxel = the mean of the points inside; the grid is anchored at min_bound - voxel_size / 2."""
+    points = np.asarray(points, dtype=np.float64)
+    if len(points) == 0:
+        return points
+    origin = points.min(axis=0) - 0.5 * voxel_size
+    idx = np.floor((points - origin) / voxel_size).astype(np.int64)
+    _, inv_, cnt = np.unique(idx, axis=0, return_inverse=True, return_counts=True)
+    out = np.zeros((len(cnt), 3))
+    np.add.at(out, inv_.reshape(-1), points)
+    return out / cnt[:, None]

@@ -25,6 +25,12 @@ def fold_state_dict(sd) -> tuple:
                 v = sd[pre + name]
                 return np.asarray(v.detach().cpu().numpy() if hasattr(v, "detach") else v, dtype=np.float32)
         return None
+    norm_keys = [k for k in sd if any(part.startswith("bn") and part[2:].isdigit() for part in k.split("."))]
+    if norm_keys:
+        # Decoder(weight_norm=False, norm_layers=[...]) inserts nn.LayerNorm modules `bn{l}` between Linear and ReLU
+        # (deep_sdf_decoder.py:57-62, 96-99): folding only the Linear layers would evaluate a different network.
+        raise NotImplementedError("LayerNorm ('bn*') parameters found (%s ...): only weight-normalised or plain "
+                                  "Linear stacks are supported" % norm_keys[0])
     Ws, bs = [], []
     for l in range(N_LIN):
         v = get(f"lin{l}.weight_v")
@@ -109,6 +115,9 @@ def config_decoder(experiment_directory: str, checkpoint: str = "latest") -> Dec
     ns = specs["NetworkSpecs"]
     if list(ns["dims"]) != [512] * 8 or list(ns["latent_in"]) != [4] or ns.get("xyz_in_all") or ns.get("use_tanh"):
         raise NotImplementedError("only the shipped 8x512, latent_in=[4] DeepSDF architecture is supported")
+    if ns.get("norm_layers") and not ns.get("weight_norm", False):
+        raise NotImplementedError("norm_layers without weight_norm inserts LayerNorm modules "
+                                  "(deep_sdf_decoder.py:57-62): not supported")
     saved = torch.load(os.path.join(experiment_directory, "ModelParameters", checkpoint + ".pth"),
                        map_location="cpu")
     Ws, bs = fold_state_dict(saved["model_state_dict"])

@@ -172,3 +172,17 @@ class PrecisionRecall:
         re = sum(self.re_dict[t]) / len(self.re_dict[t])
         f1 = sum(self.f1_dict[t]) / len(self.f1_dict[t])
         return pr, re, f1, t
+
+    def compute_at_all_thresholds(self):
+        """precision_recall.py:90-94: per-threshold means over the updates, in threshold order."""
+        mean = lambda d: [sum(d[t]) / len(d[t]) for t in self.thresholds]
+        return mean(self.pr_dict), mean(self.re_dict), mean(self.f1_dict)
+
+    def compute_auc(self):
+        """precision_recall.py:68-88: Simpson area under the three curves, normalised by the area of a perfect
+        predictor (a curve of ones on the same grid -- note the curves themselves are in percent)."""
+        from scipy.integrate import simpson
+        dx = self.thresholds[1] - self.thresholds[0]
+        perfect = simpson(np.ones_like(self.thresholds), dx=dx)
+        pr, re, f1 = self.compute_at_all_thresholds()
+        return simpson(pr, dx=dx) / perfect, simpson(re, dx=dx) / perfect, simpson(f1, dx=dx) / perfect

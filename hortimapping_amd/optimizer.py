@@ -9,6 +9,7 @@ tensors and unpacks results; no arithmetic of the hot path happens here and ther
 from __future__ import annotations
 
 import ctypes
+import functools
 from dataclasses import dataclass
 from typing import List, Optional, Sequence
 
@@ -20,6 +21,7 @@ from .decoder import DecoderWeights
 
 STATUS_CONV_G, STATUS_CONV_C, STATUS_CONV_P, STATUS_MAX_ITER, STATUS_INVALID, STATUS_SOLVE_FAILED = 1, 2, 4, 8, 16, 32
 STATUS_FRAME_SKIPPED = 64       # informational: a frame was left out in some iteration (optimizer.py:130-132)
+STATUS_LIMIT = 128              # the instance exceeds a workspace capacity: refused / stopped, never truncated
 
 _vp = ctypes.c_void_p
 
@@ -120,9 +122,14 @@ class Result:
     status: int
 
 
+@functools.lru_cache(maxsize=256)
+def _select_frames(n_all: int, n_frame: int):
+    return tuple(int(i) for i in np.linspace(0, n_all - 1, min(n_frame, n_all)).astype(np.int32))
+
+
 def select_frames(n_all: int, n_frame: int) -> np.ndarray:
     """optimizer.py:77-78: np.linspace(0, F_all-1, min(n_frame, F_all)).astype(int32)."""
-    return np.linspace(0, n_all - 1, min(int(n_frame), n_all)).astype(np.int32)
+    return np.asarray(_select_frames(int(n_all), int(n_frame)), dtype=np.int32)
 
 
 class Workspace:
@@ -147,71 +154,121 @@ class Workspace:
     def nbytes(self):
         return int(_lib.lib().hm_workspace_bytes(self.handle))
 
+    def release(self):
+        if getattr(self, "handle", None):
+            _lib.lib().hm_workspace_destroy(self.handle)
+            self.handle = None
+
     def __del__(self):
         try:
-            if getattr(self, "handle", None):
-                _lib.lib().hm_workspace_destroy(self.handle)
-                self.handle = None
+            self.release()
         except Exception:
             pass
 
 
+def _cat_f32(tensors):
+    """Concatenate a list of (n_i, ...) tensors into ONE fp32 CPU tensor with a single conversion (falls back to
+    per-tensor conversion when devices / dtypes are mixed)."""
+    if len(tensors) == 0:
+        return torch.zeros(0, dtype=torch.float32)
+    with torch.no_grad():
+        try:
+            return torch.cat(tensors).to("cpu", torch.float32)
+        except (RuntimeError, TypeError):
+            return torch.cat([t.to("cpu", torch.float32) for t in tensors])
+
+
+def _scatter_rows(dst2d, counts, row_base, src):
+    """dst2d[row_base[s] + j] = src[offset(s) + j] for j < counts[s]: ragged segments into a padded table, vectorised."""
+    counts = np.asarray(counts, dtype=np.int64)
+    row_base = np.asarray(row_base, dtype=np.int64)
+    total = int(counts.sum())
+    if total == 0:
+        return
+    c = int(counts[0])
+    if len(counts) > 1 and (counts == c).all():
+        # uniform segments at a constant stride (the common case: equal point / ray counts): one strided block copy
+        step = np.diff(row_base)
+        st = int(step[0])
+        if (step == st).all() and st >= c and int(row_base[0]) + st * len(counts) <= dst2d.shape[0] + (st - c):
+            n = len(counts)
+            flat = dst2d[int(row_base[0]):int(row_base[0]) + st * (n - 1) + c]
+            torch.as_strided(flat, (n, c) + tuple(dst2d.shape[1:]),
+                             (st * dst2d.stride(0), dst2d.stride(0)) + tuple(dst2d.stride()[1:])).copy_(
+                src.view((n, c) + tuple(dst2d.shape[1:])))
+            return
+    seg = np.repeat(np.arange(len(counts)), counts)
+    start = np.concatenate([[0], np.cumsum(counts)[:-1]])
+    idx = row_base[seg] + (np.arange(total) - start[seg])
+    dst2d[torch.from_numpy(idx)] = src
+
+
 class PackedBatch:
-    """Padded device tensors for a list of instances (the layout `hm_batch` documents)."""
+    """Padded device tensors for a list of instances (the layout `hm_batch` documents).  Packing is vectorised: the
+    Python loops only collect tensor references; the ragged -> padded copies are one concatenation + one indexed
+    store per array, staged in pinned host memory and uploaded asynchronously (4096 instances pack in milliseconds)."""
 
     def __init__(self, instances: Sequence[Instance], L: int, n_frame: int, device, F_cap=None, R_cap=None,
                  N_cap=None, joint=True):
         B = len(instances)
         self.B = B
         f32, i32 = torch.float32, torch.int32
-        n_pts = [int(inst.points_w.shape[0]) for inst in instances]
-        N = max(N_cap or 0, max(n_pts))
-        pts = torch.zeros(B, N, 3, dtype=f32)
-        for b, inst in enumerate(instances):
-            pts[b, :n_pts[b]] = inst.points_w.detach().to("cpu", f32)
+        pin = torch.cuda.is_available()
+
+        def host(*shape, dtype=f32):
+            return torch.zeros(*shape, dtype=dtype, pin_memory=pin)
+
+        def up(t):
+            return t.to(device, non_blocking=True)
+
+        n_pts = np.array([int(inst.points_w.shape[0]) for inst in instances], dtype=np.int64)
+        N = max(N_cap or 0, int(n_pts.max()))
+        pts = host(B, N, 3)
+        _scatter_rows(pts.view(B * N, 3), n_pts, np.arange(B) * N, _cat_f32([inst.points_w for inst in instances]))
         self.points_stride = N
-        self.points_w = pts.to(device)
-        self.n_points = torch.tensor(n_pts, dtype=i32, device=device)
-        self.latent = torch.stack([inst.latent.detach().to("cpu", f32).reshape(L) for inst in instances]).contiguous().to(device)
-        self.T_ow = torch.stack([inst.T_ow.detach().to("cpu", f32).reshape(16) for inst in instances]).contiguous().to(device)
-        self.cube_radius = torch.tensor([float(inst.cube_radius) for inst in instances], dtype=f32, device=device)
-        self.pose_known = torch.tensor([int(bool(inst.pose_known)) for inst in instances], dtype=i32, device=device)
+        self.points_w = up(pts)
+        self.n_points = up(torch.from_numpy(n_pts.astype(np.int32)))
+        lat = host(B, L)
+        lat.copy_(_cat_f32([inst.latent.reshape(-1) for inst in instances]).view(B, L))
+        Tow = host(B, 16)
+        Tow.copy_(_cat_f32([inst.T_ow for inst in instances]).view(B, 16))
+        self.latent, self.T_ow = up(lat), up(Tow)
+        self.cube_radius = up(torch.tensor([float(inst.cube_radius) for inst in instances], dtype=f32))
+        self.pose_known = up(torch.tensor([int(bool(inst.pose_known)) for inst in instances], dtype=i32))
         self.iter_count = torch.zeros(B, dtype=i32, device=device)
         self.status = torch.zeros(B, dtype=i32, device=device)
         self.F = self.R = 0
         self.T_wc = self.rays = self.depth = self.n_fg = self.n_bg = self.n_frames = None
         if joint:
-            sel = []
-            for inst in instances:
-                rd = inst.render_data
-                sel.append(select_frames(len(rd["T_wc"]), n_frame))
-            F = max(F_cap or 0, max(len(s) for s in sel), 1)
-            R = max(R_cap or 0, 1)
-            for inst, s in zip(instances, sel):
-                for idx in s:
-                    R = max(R, int(inst.render_data["rays_fg"][idx].shape[0] + inst.render_data["rays_bg"][idx].shape[0]))
-            T_wc = torch.zeros(B, F, 16, dtype=f32)
-            rays = torch.zeros(B, F, R, 3, dtype=f32)
-            depth = torch.zeros(B, F, R, dtype=f32)
-            n_fg = torch.zeros(B, F, dtype=i32)
-            n_bg = torch.zeros(B, F, dtype=i32)
-            n_frames = torch.zeros(B, dtype=i32)
-            for b, (inst, s) in enumerate(zip(instances, sel)):
-                rd = inst.render_data
-                n_frames[b] = len(s)
-                for k, idx in enumerate(s):
-                    fg, bg = rd["rays_fg"][idx].detach().to("cpu", f32), rd["rays_bg"][idx].detach().to("cpu", f32)
-                    nf, nb = fg.shape[0], bg.shape[0]
-                    T_wc[b, k] = rd["T_wc"][idx].detach().to("cpu", f32).reshape(16)
-                    rays[b, k, :nf] = fg
-                    rays[b, k, nf:nf + nb] = bg
-                    depth[b, k, :nf] = rd["depth_fg"][idx].detach().to("cpu", f32)
-                    depth[b, k, nf:nf + nb] = rd["depth_bg"][idx].detach().to("cpu", f32)
-                    n_fg[b, k] = nf
-                    n_bg[b, k] = nb
+            sel = [_select_frames(len(inst.render_data["T_wc"]), int(n_frame)) for inst in instances]
+            nfr = np.array([len(s) for s in sel], dtype=np.int64)
+            F = max(F_cap or 0, int(nfr.max()), 1)
+            # one entry per selected (instance, frame), in (b, k) order
+            first = np.repeat(np.arange(B) * F, nfr)
+            slot = first + (np.arange(int(nfr.sum())) - np.repeat(np.cumsum(nfr) - nfr, nfr))
+            rds = [inst.render_data for inst in instances]
+            fg = [rd["rays_fg"][i] for rd, s in zip(rds, sel) for i in s]
+            bg = [rd["rays_bg"][i] for rd, s in zip(rds, sel) for i in s]
+            dfg = [rd["depth_fg"][i] for rd, s in zip(rds, sel) for i in s]
+            dbg = [rd["depth_bg"][i] for rd, s in zip(rds, sel) for i in s]
+            Twc = [rd["T_wc"][i] for rd, s in zip(rds, sel) for i in s]
+            nf = np.array([t.shape[0] for t in fg], dtype=np.int64)
+            nb = np.array([t.shape[0] for t in bg], dtype=np.int64)
+            R = max(R_cap or 0, int((nf + nb).max()) if len(nf) else 0, 1)
+            T_wc, rays, depth = host(B, F, 16), host(B, F, R, 3), host(B, F, R)
+            n_fg, n_bg = np.zeros(B * F, np.int32), np.zeros(B * F, np.int32)
+            n_fg[slot], n_bg[slot] = nf, nb
+            r2, d2 = rays.view(B * F * R, 3), depth.view(B * F * R)
+            _scatter_rows(r2, nf, slot * R, _cat_f32(fg).view(-1, 3))
+            _scatter_rows(r2, nb, slot * R + nf, _cat_f32(bg).view(-1, 3))
+            _scatter_rows(d2, nf, slot * R, _cat_f32(dfg).view(-1))
+            _scatter_rows(d2, nb, slot * R + nf, _cat_f32(dbg).view(-1))
+            T_wc.view(B * F, 16)[torch.from_numpy(slot)] = _cat_f32(Twc).view(-1, 16)
             self.F, self.R = F, R
-            self.T_wc, self.rays, self.depth = T_wc.to(device), rays.to(device), depth.to(device)
-            self.n_fg, self.n_bg, self.n_frames = n_fg.to(device), n_bg.to(device), n_frames.to(device)
+            self.T_wc, self.rays, self.depth = up(T_wc), up(rays), up(depth)
+            self.n_fg = up(torch.from_numpy(n_fg).view(B, F))
+            self.n_bg = up(torch.from_numpy(n_bg).view(B, F))
+            self.n_frames = up(torch.from_numpy(nfr.astype(np.int32)))
 
     def as_struct(self) -> HmBatch:
         p = lambda t: 0 if t is None else t.data_ptr()
@@ -244,24 +301,51 @@ def run_packed(ws: Workspace, cfg: HmOptCfg, pb: PackedBatch, mode: int, debug: 
     _lib.check(rc, "hm_optimize_batch")
 
 
+def _grown_workspace(dec, old: Optional[Workspace], B, N, F, R, M) -> Workspace:
+    """A workspace that fits (B, N, F, R, M) and everything `old` fitted (grow-only, so a per-fruit loop settles on
+    one allocation after the largest instance has been seen)."""
+    if old is not None and old.dec is dec:
+        l = old.limits
+        B, N = max(B, l.max_batch), max(N, l.max_points)
+        F, R, M = max(F, l.max_frames), max(R, l.max_rays), max(M, l.max_samples)
+        old.release()                     # free before allocating the larger one
+    return Workspace(dec, B, N, F, R, M)
+
+
 def optimize_batch(dec: DecoderWeights, opt: dict, instances: Sequence[Instance], shape_only: bool = False,
-                   workspace: Optional[Workspace] = None, device="cuda", debug: Optional[dict] = None) -> List[Result]:
-    """Optimise all `instances` concurrently; results are returned in input order (identical instance indexing)."""
+                   workspace: Optional[Workspace] = None, device="cuda", debug: Optional[dict] = None,
+                   cache: Optional[dict] = None) -> List[Result]:
+    """Optimise all `instances` concurrently; results are returned in input order (identical instance indexing).
+    `cache` (a dict owned by the caller, e.g. the drop-in `Optimizer`) keeps the workspace between calls: the
+    reference's usage pattern is one fruit per call, and a fresh hipMalloc + hipMemset + hipFree of the workspace per
+    call would dominate its latency."""
     if len(instances) == 0:
         return []
     cfg = opt_cfg_from_dict(opt)
     L = dec.latent_dim
-    pb = PackedBatch(instances, L, int(opt["render"]["n_frame"]), device, joint=not shape_only)
-    M = cfg.n_sample_on_ray
-    if workspace is None or not workspace.fits(pb.B, pb.points_stride, pb.F, pb.R, M if not shape_only else 0):
-        workspace = Workspace(dec, pb.B, pb.points_stride, pb.F, pb.R, 0 if shape_only else M)
-    elif not shape_only:
-        # the workspace strides are capacities: re-pack to the workspace's frame/ray capacity
+    if workspace is None and cache is not None:
+        workspace = cache.get("ws")
+        if workspace is not None and (workspace.handle is None or workspace.dec is not dec):
+            workspace = None
+    n_frame = int(opt["render"]["n_frame"])
+    M = 0 if shape_only else cfg.n_sample_on_ray
+    l = workspace.limits if workspace is not None else None
+    # pack straight to the workspace's frame / ray capacities when there is one (its strides ARE the capacities)
+    pb = PackedBatch(instances, L, n_frame, device, joint=not shape_only,
+                     F_cap=l.max_frames if l else None, R_cap=l.max_rays if l else None)
+    if workspace is None or not workspace.fits(pb.B, pb.points_stride, pb.F, pb.R, M):
+        workspace = _grown_workspace(dec, workspace if cache is not None else None, pb.B, pb.points_stride, pb.F, pb.R, M)
         l = workspace.limits
-        if (pb.F, pb.R) != (l.max_frames, l.max_rays):
-            pb = PackedBatch(instances, L, int(opt["render"]["n_frame"]), device, F_cap=l.max_frames, R_cap=l.max_rays)
+        if not shape_only and (pb.F, pb.R) != (l.max_frames, l.max_rays):
+            pb = PackedBatch(instances, L, n_frame, device, F_cap=l.max_frames, R_cap=l.max_rays)
+    if cache is not None:
+        cache["ws"] = workspace
     run_packed(workspace, cfg, pb, 1 if shape_only else 0, debug)
-    lat, T, it, st = pb.latent.cpu(), pb.T_ow.cpu(), pb.iter_count.cpu(), pb.status.cpu()
+    # one D2H transfer for the whole batch (the copy synchronises with the stream the optimisation was enqueued on)
+    rec = torch.cat([pb.latent, pb.T_ow, pb.iter_count.to(torch.float32)[:, None],
+                     pb.status.to(torch.float32)[:, None]], dim=1).cpu()
+    lat, T = rec[:, :L], rec[:, L:L + 16]
+    it, st = rec[:, L + 16].to(torch.int64), rec[:, L + 17].to(torch.int64)
     return [Result(lat[b].clone(), T[b].reshape(4, 4).clone(), int(it[b]), int(st[b])) for b in range(pb.B)]
 
 
@@ -295,13 +379,14 @@ class Optimizer(object):
         self.mesher = mesher
         self.vis = vis
         self.log_on = cfg.get("vis", {}).get("log_on", False)
-        self._ws = None
+        self._cache = {}                      # persistent (grow-only) workspace across calls
 
     def _device(self):
         return "cuda" if str(self.dev).startswith("cuda") else self.dev
 
     def optimize_batch(self, instances: Sequence[Instance], shape_only: bool = False) -> List[Result]:
-        return optimize_batch(self.decoder, self.opt_cfg, instances, shape_only, None, self._device())
+        return optimize_batch(self.decoder, self.opt_cfg, instances, shape_only, None, self._device(),
+                              cache=self._cache)
 
     def shape_pose_joint_opt(self, latent, T_ow_torch, render_data, points_w_torch, cube_radius, cur_color=None,
                              pose_known=False):

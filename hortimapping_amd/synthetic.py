@@ -40,7 +40,7 @@ def layer_shapes(latent_dim: int, hidden: int = HIDDEN):
 def make_synthetic_decoder(latent_dim: int, seed: int = 0, r0: float = 0.04,
                            aniso=(1.0, 1.0, 1.0), latent_gain: float = 0.1,
                            noise: float = 0.01, hidden: int = HIDDEN,
-                           wn_perturb: float = 0.0, freq_sigma: float = 2.0):
+                           wn_perturb: float = 0.0, freq_sigma: float = 2.0, bias_sigma: float = 0.0):
     """Return a dict of fp32 arrays describing a weight-normed decoder.
 
     Keys: ``lin{l}.weight_v``, ``lin{l}.weight_g`` (l = 0..7), ``lin8.weight``,
@@ -48,7 +48,8 @@ def make_synthetic_decoder(latent_dim: int, seed: int = 0, r0: float = 0.04,
     weight of a weight-normed layer is ``g * v / ||v||_row`` (reference
     `deep_sdf_decoder.py:49-54`, torch ``weight_norm`` dim=0).  With
     ``wn_perturb == 0`` we set ``g = ||v||`` so the effective weight is ``v``;
-    a non-zero value perturbs ``g`` to exercise the folding code.
+    a non-zero value perturbs ``g`` to exercise the folding code.  ``bias_sigma`` adds Gaussian noise to the hidden
+    biases from a SEPARATE stream (seed + 7919), so the weight draws of existing fixtures do not move.
     """
     L, H = int(latent_dim), int(hidden)
     rs = np.random.RandomState(seed)
@@ -92,9 +93,12 @@ def make_synthetic_decoder(latent_dim: int, seed: int = 0, r0: float = 0.04,
     W[8] = np.full((1, H), 4.0 / H)
 
     out = {"latent_dim": L, "hidden": H}
+    rsb = np.random.RandomState(seed + 7919)
     for l in range(N_LIN):
         w = W[l].astype(np.float32)
         b = np.zeros(w.shape[0], dtype=np.float32)
+        if bias_sigma and l < 8:
+            b = (bias_sigma * rsb.randn(w.shape[0])).astype(np.float32)
         if l == 8:
             b[0] = -r0
             out["lin8.weight"] = w

@@ -13,13 +13,21 @@ from .decoder import DecoderWeights
 _CONVERTED = {}
 
 
+def _module_fingerprint(module):
+    """Identity AND content version of an nn.Module's parameters: `id()` alone would hand back stale packed weights
+    after an in-place update (optimizer step, load_state_dict) or after the id is reused by a new module."""
+    return tuple((k, v.data_ptr(), v._version, tuple(v.shape)) for k, v in module.state_dict(keep_vars=True).items())
+
+
 def as_weights(decoder) -> DecoderWeights:
+    """`decoder`: a DecoderWeights bundle, or the reference's nn.Module (converted once per parameter version)."""
     if isinstance(decoder, DecoderWeights):
         return decoder
-    key = id(decoder)
-    if key not in _CONVERTED:
-        _CONVERTED[key] = DecoderWeights.from_module(decoder)
-    return _CONVERTED[key]
+    key, fp = id(decoder), _module_fingerprint(decoder)
+    hit = _CONVERTED.get(key)
+    if hit is None or hit[0] != fp:
+        _CONVERTED[key] = (fp, DecoderWeights.from_module(decoder))
+    return _CONVERTED[key][1]
 
 
 def _pack_points(x: torch.Tensor, device):

@@ -33,6 +33,11 @@ typedef struct hm_workspace_s* hm_workspace_t;
 #define HM_STATUS_SOLVE_FAILED 32 /* normal matrix not positive definite / non-finite step             */
 #define HM_STATUS_FRAME_SKIPPED 64 /* optimizer.py:130-132 'This frame is not valid': in some iteration a frame had
                                       fewer than min_valid_sample ball-valid samples and was left out (informational) */
+#define HM_STATUS_LIMIT 128       /* the instance does not fit the workspace (n_points > max_points, n_frames >
+                                      max_frames, n_fg + n_bg > max_rays, or more Jacobian samples than
+                                      max_grad_samples): it is NOT optimised (iter_count 0, state untouched) or, for
+                                      the Jacobian-sample cap, stopped at the iteration that overflowed.  The reference
+                                      has no capacities; this bit is how a truncation is reported instead of hidden */
 
 const char* hm_last_error(void);
 
@@ -110,7 +115,9 @@ typedef struct hm_limits {
  *   iter_count, status [B] outputs.  Instance order is preserved (result b belongs to input b). */
 typedef struct hm_batch {
   int B;
-  int points_stride;
+  int points_stride;       /* rows between instances in d_points_w; must be <= limits.max_points.  The frame and ray
+                              strides of T_wc / rays / depth / n_fg / n_bg are the workspace's max_frames and
+                              max_rays (there are no separate fields): pack to the workspace capacities */
   const float* d_points_w;
   const int* d_n_points;
   const float* d_T_wc;
@@ -169,6 +176,13 @@ int hm_render_residuals(hm_workspace_t ws, const hm_opt_cfg* cfg, const hm_batch
  * the f16x3 decoder kernel / of the solve kernel writes shader-clock stamps per stage into it (scripts/gpu_trace_*.py). */
 void hm_debug_set_trace(long long* d_buf);      /* [NSTAGE * 4 + 1] or NULL */
 void hm_debug_set_k5_trace(long long* d_buf);   /* [6] or NULL */
+
+/* ---- unit hooks (tests): the device functions of the solve kernel / normal-equation kernel on caller-supplied values.
+ * hm_debug_exp_map replaces exp_sim3 (sim3 != 0; wild_completion/utils.py:279-324) / exp_se3 (:220-254) for n tangents
+ * [n][7] (translation, rotation, log-scale; the 7th entry is ignored for se3) -> [n][16] row-major 4x4.
+ * hm_debug_huber replaces get_robust_res (utils.py:343-358): d_rho[i] = w_i^2, d_robust_res[i] = w_i r_i (optional). */
+int hm_debug_exp_map(const float* d_tangents, int n, int sim3, float* d_T, void* stream);
+int hm_debug_huber(const float* d_res, int n, float threshold, float* d_rho, float* d_robust_res, void* stream);
 
 /* ---- next row: iso-surface of a decoded SDF grid; replaces convert_sdf_voxels_to_mesh
  * (wild_completion/utils.py:565-588, scikit-image marching cubes on the host) by marching tetrahedra on the GPU over the

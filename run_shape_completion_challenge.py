@@ -88,6 +88,7 @@ def main(config):
             cd_metric.update(gt, complete)
             pr_metric.update(gt, complete)
     if gt_valid and jobs:
+        pr_all, re_all, f1_all = pr_metric.compute_at_all_thresholds()      # :246 (curves over 1..10 mm)
         pr, re, f1, thre = pr_metric.compute_at_threshold(0.005)
         print("Results on the", cfg["split"], "set")                        # :262-270
         print("CD        [mm]:", cd_metric.compute() * 1e3)

@@ -73,7 +73,7 @@ def main(config):
             continue
         cur_mesh = read_ply(os.path.join(submap_folder, submap_name))
         if submap_cat == "Background":                                   # :148-151
-            bg_points = cur_mesh.sample_points_uniformly(100000, seed=42)
+            bg_points = DP.voxel_down_sample(cur_mesh.sample_points_uniformly(500000, seed=42), 0.005)
             continue
         render_data = DP.get_render_data(submap_id, frames["id"], frames["depth"], frames["pose"], img_size, invK, cfg)
         if render_data["count"] == 0:
@@ -95,16 +95,11 @@ def main(config):
     for (submap_name, submap_id, pts, _), res in zip(jobs, results):
         if res.status & STATUS_INVALID:
             print("Submap %d: not valid (no depth residuals)" % submap_id)
-        T_wo = inv(res.T_ow.numpy().astype(np.float64))
-        final_scale = det(T_wo[:3, :3]) ** (1 / 3)
-        from scipy.spatial.transform import Rotation
-        yaw, pitch, roll = Rotation.from_matrix(T_wo[:3, :3] / final_scale).as_euler("zyx", degrees=True)
         out = cfg["opt"]["outlier"]
-        if final_scale < out["scale_min"] or final_scale > out["scale_max"]:      # :238-246
-            print("Submap %d: final scale %f is an outlier, not valid" % (submap_id, final_scale))
-            continue
-        if abs(pitch) > out["rot_max_deg"] or abs(roll) > out["rot_max_deg"]:
-            print("Submap %d: final rotation (pitch %f, roll %f) is an outlier, not valid" % (submap_id, pitch, roll))
+        T_wo, final_scale, (yaw, pitch, roll), keep = DP.final_pose_check(res.T_ow.numpy().astype(np.float64), out)
+        if not keep:                                                              # :238-246
+            print("Submap %d: final scale %f / pitch %f / roll %f is an outlier, not valid"
+                  % (submap_id, final_scale, pitch, roll))
             continue
         mesh = mesh_extractor.complete_mesh(res.latent, T_wo, None)
         write_ply(mesh, os.path.join(complete_submap_folder, submap_name))       # :249-252

@@ -48,3 +48,60 @@ def test_two_rank_gather_preserves_instance_order():
         assert torch.equal(lat[:, 0], ids * 1000) and torch.equal(lat[:, 5], ids * 1000 + 5)
         assert torch.equal(T[:, 0, 0], ids + 0.5)
         assert torch.equal(it, ids.int() % 7) and torch.equal(st, (ids.int() % 3) * 8)
+
+
+def _run_bench_ranks(world, extra, port):
+    """Launch bench.py's own main() once per rank (gloo, `--stub-cpu`: the GPU optimisation is replaced by a stand-in,
+    everything around it -- argument check, shard plan, chunk loop, gather, MAX all-reduce, JSON -- is the real code)."""
+    import json
+    import subprocess
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--stub-cpu", "--gpus", str(world),
+                                       "--latent", "32", "--steps", "2", "--warmup", "1"] + extra, env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=240) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, se[-2000:]
+    lines = [l for l in outs[0][0].splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                   # exactly ONE JSON line, from rank 0
+    assert all(not l.startswith("{") for so, _ in outs[1:] for l in so.splitlines())
+    return json.loads(lines[0])
+
+
+def test_bench_rank_logic_two_ranks_strong_and_weak_scaling():
+    port = 29900 + (os.getpid() % 90)
+    # strong scaling (configs[3] in miniature): 37 instances over 2 ranks (19 + 18) in chunks of 8
+    j = _run_bench_ranks(2, ["--total", "37", "--batch", "8"], port)
+    assert j["n_gpus"] == 2 and j["scaling"] == "strong" and j["steps"] == 2 and j["warmup"] == 1
+    assert j["config"]["instances_total"] == 37 and j["config"]["instances_per_gpu"] == 19 and j["config"]["chunk"] == 8
+    assert j["value"] > 0 and abs(j["value"] - 37 * 2 / (j["ms_per_step"] * 2e-3)) < 1e-2 * j["value"]
+    assert "stub" in j and "roofline" not in j               # the stand-in never passes for a measurement
+    # weak scaling: 64 per rank
+    j = _run_bench_ranks(2, [], port + 1)
+    assert j["scaling"] == "weak" and j["config"]["instances_total"] == 128 and j["config"]["instances_per_gpu"] == 64
+
+
+def test_bench_refuses_a_gpu_count_that_does_not_match_the_launch():
+    import subprocess
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--stub-cpu", "--gpus", "2"], env=env,
+                       capture_output=True, text=True, timeout=120)
+    assert p.returncode != 0 and "WORLD_SIZE=1" in (p.stderr + p.stdout)
+
+
+def test_bench_shard_plan():
+    sys.path.insert(0, ROOT)
+    import bench
+    ids, chunks, n = bench.plan_shard(3, 8, 64, 0, 256)                  # weak: rank 3 of 8
+    assert ids == list(range(192, 256)) and chunks == [(0, 64)] and n == 512
+    seen = []
+    for r in range(8):                                                   # configs[3]: 4096 over 8 GPUs, chunks of 256
+        ids, chunks, n = bench.plan_shard(r, 8, 64, 4096, 256)
+        assert n == 4096 and len(ids) == 512 and chunks == [(0, 256), (256, 512)]
+        seen += ids
+    assert seen == list(range(4096))
+    ids, chunks, n = bench.plan_shard(1, 2, 64, 37, 8)                   # uneven: 19 + 18
+    assert ids == list(range(19, 37)) and chunks == [(0, 8), (8, 16), (16, 18)]

@@ -78,3 +78,41 @@ def test_frame_without_enough_ball_samples_is_skipped_like_the_reference():
         assert r.iter_count == n == 4 and r.status == (8 | 64 if j == 0 else 8)     # 64 = HM_STATUS_FRAME_SKIPPED
         assert rel(r.latent, z) < 2e-3 and rel(r.T_ow, T) < 1e-4
     assert int(counts[0, 0]) < int(counts[1, 0])         # the skipped frame's samples are not counted for instance 0
+
+
+def test_instance_beyond_a_capacity_is_refused_not_truncated():
+    """C-ABI callers can lie about per-instance counts (the Python packer cannot): an instance whose n_points / ray
+    counts exceed the packed strides, or whose Jacobian samples exceed max_grad_samples, must come back flagged
+    HM_STATUS_LIMIT (128) and its neighbours in the batch must be untouched by it -- never a silently wrong H."""
+    from hortimapping_amd import _lib, optimizer as HO, workloads as W
+    dec, od, dicts = make(32, 4, 0.04, (1.0, 0.75, 1.3), [0, 1, 2], n_pts=100, n_frames=1, n_fg=60, n_bg=24)
+    insts = [W.to_instance(d, pose_known=True) for d in dicts]
+    dev = torch.device("cuda")
+    cfg = HO.opt_cfg_from_dict(W.c2_opt_cfg(max_iter=3))
+    good = HO.optimize_batch(dec, W.c2_opt_cfg(max_iter=3), insts)
+    # (a) n_points[1] larger than the stride, n_fg[2] + n_bg[2] larger than the ray capacity
+    pb = HO.PackedBatch(insts, 32, 1, dev, joint=True)
+    ws = HO.Workspace(dec, 3, pb.points_stride, pb.F, pb.R, 16)
+    lat0 = pb.latent.clone()
+    pb.n_points[1] = pb.points_stride + 1
+    pb.n_fg[2, 0] = pb.R
+    HO.run_packed(ws, cfg, pb, 0)
+    torch.cuda.synchronize()
+    st, it = pb.status.cpu(), pb.iter_count.cpu()
+    assert int(st[0]) == 8 and int(it[0]) == 3
+    assert torch.equal(pb.latent[0].cpu(), good[0].latent)
+    for b in (1, 2):
+        assert int(st[b]) == HO.STATUS_LIMIT and int(it[b]) == 0
+        assert torch.equal(pb.latent[b], lat0[b])                                   # state untouched
+    # (b) a points_stride beyond the workspace's capacity is refused on the host
+    ws_small = HO.Workspace(dec, 3, 64, pb.F, pb.R, 16)
+    pb2 = HO.PackedBatch(insts, 32, 1, dev, joint=True)
+    with pytest.raises(_lib.HortiHipError, match="points_stride"):
+        HO.run_packed(ws_small, cfg, pb2, 0)
+    # (c) fewer Jacobian-sample slots than surviving samples: reported, instance stopped
+    ws_cap = HO.Workspace(dec, 3, pb2.points_stride, pb2.F, pb2.R, 16, max_grad_samples=64)
+    HO.run_packed(ws_cap, cfg, pb2, 0)
+    torch.cuda.synchronize()
+    st = pb2.status.cpu()
+    assert all(int(s) & HO.STATUS_LIMIT for s in st) and all(int(s) & HO.STATUS_SOLVE_FAILED for s in st)
+    assert int(pb2.iter_count.max()) == 0
