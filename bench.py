@@ -43,6 +43,9 @@ PRECISIONS = {
     "f16x3f_f16b": (PEAK_F16_MFMA_TFLOPS, "k_decoder_h<1,0,1>",
                     "mixed: forward (residuals) as f16x3, input-gradient backward (Jacobians) as ONE fp16 MFMA pass "
                     "on the hi parts (J ~1e-3 relative); not fp32-class, never the default line"),
+    "f16": (PEAK_F16_MFMA_TFLOPS, "k_decoder_p<1,0>",
+            "f16 = plain fp16 MFMA decoder (BASELINE.json configs[4]): one pass per product, fp16 activations, 128-query "
+            "tiles; fp16-class results (~1e-3), not the reference's fp32; never the default line"),
 }
 TRAFFIC_FILE = os.path.join("profiles", "r02_traffic.json")
 
@@ -322,7 +325,7 @@ def main(argv=None):
             out["roofline"] = roofline(args.precision, ms_tot, n_launch)
     if not stub and not args.no_exact and world == 1 and not strong:
         # the same job in the other decoder arithmetics, one timed step each, for reference next to the primary line
-        for other, key in (("f32", "exact_f32"), ("f16x3f_f16b", "mixed_f16x3f_f16b")):
+        for other, key in (("f32", "exact_f32"), ("f16x3f_f16b", "mixed_f16x3f_f16b"), ("f16", "plain_f16")):
             if other == args.precision:
                 continue
             dt2, ms2, nl2, allrec2 = measure(other, 1, 1)

@@ -61,7 +61,9 @@ struct DecoderDev {
 
 struct hm_decoder_s {
   hm::DecoderDev dev;
-  int precision;       // 0: exact fp32 MFMA, 1: fp16 hi/lo split (3 fp16 MFMA passes, ~2^-22 relative)
+  int precision;       // 0: exact fp32 MFMA, 1: fp16 hi/lo split (3 fp16 MFMA passes, ~2^-22 relative),
+                       // 2: as 1 in the forward stages, ONE fp16 pass in the backward stages (Jacobians ~1e-3),
+                       // 3: plain fp16 MFMA everywhere (hm_decoder_p.hip, 128-query tiles; fp16-class results)
   void* d_blob;        // one allocation holding every packed array
   size_t blob_bytes;
   int L;

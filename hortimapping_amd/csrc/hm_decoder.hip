@@ -395,7 +395,10 @@ int launch_decoder(const hm_decoder_s* dec, int B, const float* d_pts, const int
                    int n_stride, const float* d_c0, const float* d_c4, float* d_y, float* d_J, int ldJ,
                    int pose_dim, int mode, hipStream_t stream, int tag) {
   if (n_stride % TQ != 0) { hm_set_error("n_stride must be a multiple of %d", TQ); return -1; }
-  if (dec->precision == 1)
+  if (dec->precision == 3)
+    return launch_decoder_p(dec, B, d_pts, d_nq, d_active, n_stride, d_c0, d_c4, d_y, d_J, ldJ, pose_dim, mode,
+                            stream, tag);
+  if (dec->precision == 1 || dec->precision == 2)
     return launch_decoder_h(dec, B, d_pts, d_nq, d_active, n_stride, d_c0, d_c4, d_y, d_J, ldJ, pose_dim, mode,
                             stream, tag);
   DecodeArgs a;

@@ -174,18 +174,98 @@ __device__ __forceinline__ void gemm_loop_h(f32x16 (&acc)[2][2], const f16x8* __
 #undef HM_STEP
 }
 
-// X[k][q] as float for k = 8*grp + j (VALU side paths)
-__device__ __forceinline__ void load_group(const f16x8* xh, const f16x8* xl, int grp, int q, float (&x)[8]) {
-  const f16x8 h = xh[grp * TQ + q], l = xl[grp * TQ + q];
+
+// ---- one-pass K loop (precision 2, backward stages only): G W = Gh Wh, a single fp16 MFMA pass on the hi parts.
+// A K-step is 4 MFMAs (128 matrix-pipe cycles per wave) instead of 12, so the weight fetches run THREE steps ahead
+// (ring of four hi-only sets) and the activation reads one; the loop is unrolled by four (branch-free groups).
+struct ASet1 { f16x8 h0, h1; };
+struct BSet1 { f16x8 h0, h1; };
+
+template <bool U0, bool U1>
+__device__ __forceinline__ void step_h1(f32x16 (&acc)[2][2], const ASet1& a, const BSet1& b, ASet1& an, BSet1& bn,
+                                        const f16x8* __restrict__ wp0, const f16x8* __restrict__ wp1, int ka,
+                                        const f16x8* xh, int kb, int xo) {
+  const f16x8* w0 = wp0 + ka * 128;
+  const f16x8* w1 = wp1 + ka * 128;
+  const f16x8* ph = xh + kb * 2 * TQ + xo;
+  HM_FENCE();
+  if (U0) { HM_MFMA(a.h0, b.h0, acc[0][0]); HM_MFMA(a.h0, b.h1, acc[0][1]); }
+  else    { HM_MFMA(a.h1, b.h0, acc[1][0]); HM_MFMA(a.h1, b.h1, acc[1][1]); }
+  HM_FENCE(); bn.h0 = ph[0]; bn.h1 = ph[32]; HM_FENCE();
+  if (U0 && U1) { HM_MFMA(a.h1, b.h0, acc[1][0]); HM_MFMA(a.h1, b.h1, acc[1][1]); }
+  HM_FENCE();
+  if (U0) an.h0 = w0[0];
+  if (U1) an.h1 = w1[0];
+  HM_FENCE();
+}
+
+template <bool U0, bool U1>
+__device__ __forceinline__ void gemm_loop_h1(f32x16 (&acc)[2][2], const f16x8* __restrict__ wp0,
+                                             const f16x8* __restrict__ wp1, int n_k16, const f16x8* xh, int lane) {
+  const int xo = (lane >> 5) * TQ + (lane & 31);
+  const int last = n_k16 - 1;
+  ASet1 a0 = {}, a1 = {}, a2 = {}, a3 = {};
+  BSet1 b0, b1 = {};
+  auto lda = [&](ASet1& a, int k) {
+    k = k < last ? k : last;
+    if (U0) a.h0 = wp0[k * 128];
+    if (U1) a.h1 = wp1[k * 128];
+  };
+  lda(a0, 0); lda(a1, 1); lda(a2, 2);
+  b0.h0 = xh[xo]; b0.h1 = xh[xo + 32];
+#define HM_STEP1(AS, BS, ANEXT, BNEXT, I)                                                          \
+  if (HM_COND(I)) {                                                                                \
+    step_h1<U0, U1>(acc, AS, BS, ANEXT, BNEXT, wp0, wp1, (ks + (I) + 3 < n_k16) ? ks + (I) + 3 : last, xh, \
+                    (ks + (I) + 1 < n_k16) ? ks + (I) + 1 : last, xo);                             \
+  }
+  int ks = 0;
+#define HM_COND(I) true
+  for (; ks + 4 <= n_k16; ks += 4) {
+    HM_STEP1(a0, b0, a3, b1, 0)
+    HM_STEP1(a1, b1, a0, b0, 1)
+    HM_STEP1(a2, b0, a1, b1, 2)
+    HM_STEP1(a3, b1, a2, b0, 3)
+  }
+#undef HM_COND
+#define HM_COND(I) (ks + (I) < n_k16)
+  if (ks < n_k16) {
+    HM_STEP1(a0, b0, a3, b1, 0)
+    HM_STEP1(a1, b1, a0, b0, 1)
+    HM_STEP1(a2, b0, a1, b1, 2)
+  }
+#undef HM_COND
+#undef HM_STEP1
+}
+
+// hi plane only (one-pass stages): 4 consecutive-row values -> 8 bytes
+__device__ __forceinline__ void hi_store(f16x4* xh4, int idx, const float (&v)[4]) {
+  f16x4 h;
 #pragma unroll
-  for (int j = 0; j < 8; ++j) x[j] = (float)h[j] + (float)l[j] * LO_UNSCALE;
+  for (int j = 0; j < 4; ++j) h[j] = (_Float16)v[j];
+  xh4[idx] = h;
+}
+
+// X[k][q] as float for k = 8*grp + j (VALU side paths)
+template <bool HI_ONLY = false>
+__device__ __forceinline__ void load_group(const f16x8* xh, const f16x8* xl, int grp, int q, float (&x)[8]) {
+  const f16x8 h = xh[grp * TQ + q];
+  if (HI_ONLY) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) x[j] = (float)h[j];
+  } else {
+    const f16x8 l = xl[grp * TQ + q];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) x[j] = (float)h[j] + (float)l[j] * LO_UNSCALE;
+  }
 }
 
 #define HM_MASK_CASES(OP) \
   case 0: OP(mk0); break; case 1: OP(mk1); break; case 2: OP(mk2); break; case 3: OP(mk3); break; \
   case 4: OP(mk4); break; case 5: OP(mk5); break; case 6: OP(mk6); break; default: OP(mk7); break;
 
-template <int MODE, int TAG>
+// BW1: precision 2 ("f16x3f_f16b"): the forward stages (residuals, ReLU masks) run the three-pass split product, the
+// eight backward stages (Jacobian rows) ONE fp16 pass on the hi parts -- 4 instead of 6 matrix passes per query.
+template <int MODE, int TAG, bool BW1>
 __global__ __launch_bounds__(512, 2) void k_decoder_h(const DecodeArgsH a) {
   __shared__ f16x8 xh[64 * TQ];    // 64 KiB: hi plane  X[k/8][q][8]
   __shared__ f16x8 xl[64 * TQ];    // 64 KiB: lo plane (scaled by 2^11)
@@ -263,7 +343,7 @@ __global__ __launch_bounds__(512, 2) void k_decoder_h(const DecodeArgsH a) {
 #pragma unroll 2
       for (int g = 0; g < 8; ++g) {
         float x[8];
-        load_group(xh, xl, 8 * w + g, lane, x);
+        load_group<BW1>(xh, xl, 8 * w + g, lane, x);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           const f32x4 wv = wx[64 * w + 8 * g + j];
@@ -301,9 +381,15 @@ __global__ __launch_bounds__(512, 2) void k_decoder_h(const DecodeArgsH a) {
       const f16x8* wp = reinterpret_cast<const f16x8*>(sh.wp);
       const f16x8* wp0 = wp + (size_t)(mb0 - sd.mb_lo) * sh.mb_stride + lane;
       const f16x8* wp1 = wp + (size_t)(mb1 - sd.mb_lo) * sh.mb_stride + lane;
-      if (u0 && u1) gemm_loop_h<true, true>(acc, wp0, wp1, sh.n_k16, xh, xl, lane);
-      else if (u0) gemm_loop_h<true, false>(acc, wp0, wp1, sh.n_k16, xh, xl, lane);
-      else if (u1) gemm_loop_h<false, true>(acc, wp0, wp1, sh.n_k16, xh, xl, lane);
+      if (BW1 && MODE == 1 && s >= 8) {
+        if (u0 && u1) gemm_loop_h1<true, true>(acc, wp0, wp1, sh.n_k16, xh, lane);
+        else if (u0) gemm_loop_h1<true, false>(acc, wp0, wp1, sh.n_k16, xh, lane);
+        else if (u1) gemm_loop_h1<false, true>(acc, wp0, wp1, sh.n_k16, xh, lane);
+      } else {
+        if (u0 && u1) gemm_loop_h<true, true>(acc, wp0, wp1, sh.n_k16, xh, xl, lane);
+        else if (u0) gemm_loop_h<true, false>(acc, wp0, wp1, sh.n_k16, xh, xl, lane);
+        else if (u1) gemm_loop_h<false, true>(acc, wp0, wp1, sh.n_k16, xh, xl, lane);
+      }
     }
     if (tr) a.trace[s * 4 + 1] = clock64();
     __syncthreads();
@@ -395,7 +481,8 @@ __global__ __launch_bounds__(512, 2) void k_decoder_h(const DecodeArgsH a) {
               float v[4];
 #pragma unroll
               for (int j = 0; j < 4; ++j) v[j] = ((bits >> (nb * 16 + 4 * g + j)) & 1u) ? dy * wv[j] : 0.f;
-              split_store(xh4, xl4, ((f4 >> 3) * TQ + nb * 32 + qa) * 2 + hi, v);
+              if (BW1) hi_store(xh4, ((f4 >> 3) * TQ + nb * 32 + qa) * 2 + hi, v);
+              else split_store(xh4, xl4, ((f4 >> 3) * TQ + nb * 32 + qa) * 2 + hi, v);
             }
           }
         }
@@ -441,7 +528,8 @@ __global__ __launch_bounds__(512, 2) void k_decoder_h(const DecodeArgsH a) {
             for (int j = 0; j < 4; ++j)
               v[j] = ((bits >> (nb * 16 + 4 * g + j)) & 1u) ? acc[sl][nb][4 * g + j] * us : 0.f;
             xmax = fmaxf(xmax, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
-            split_store(xh4, xl4, ((f4 >> 3) * TQ + nb * 32 + qa) * 2 + hi, v);
+            if (BW1) hi_store(xh4, ((f4 >> 3) * TQ + nb * 32 + qa) * 2 + hi, v);
+            else split_store(xh4, xl4, ((f4 >> 3) * TQ + nb * 32 + qa) * 2 + hi, v);
           }
         }
       }
@@ -511,9 +599,12 @@ int launch_decoder_h(const hm_decoder_s* dec, int B, const float* d_pts, const i
   a.trace = g_trace;
   const int grid = B * (n_stride / TQ);
   if (grid == 0) return 0;
-  if (mode == 0) hipLaunchKernelGGL((k_decoder_h<0, 0>), dim3(grid), dim3(512), 0, stream, a);
-  else if (tag == 0) hipLaunchKernelGGL((k_decoder_h<1, 0>), dim3(grid), dim3(512), 0, stream, a);
-  else hipLaunchKernelGGL((k_decoder_h<1, 1>), dim3(grid), dim3(512), 0, stream, a);
+  const bool bw1 = dec->precision == 2;
+  if (mode == 0) hipLaunchKernelGGL((k_decoder_h<0, 0, false>), dim3(grid), dim3(512), 0, stream, a);   // forward only
+  else if (tag == 0 && !bw1) hipLaunchKernelGGL((k_decoder_h<1, 0, false>), dim3(grid), dim3(512), 0, stream, a);
+  else if (tag == 0) hipLaunchKernelGGL((k_decoder_h<1, 0, true>), dim3(grid), dim3(512), 0, stream, a);
+  else if (!bw1) hipLaunchKernelGGL((k_decoder_h<1, 1, false>), dim3(grid), dim3(512), 0, stream, a);
+  else hipLaunchKernelGGL((k_decoder_h<1, 1, true>), dim3(grid), dim3(512), 0, stream, a);
   HM_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -63,9 +63,13 @@ __device__ inline void exp_pose(const float* x, bool sim3, float* T) {
 }
 
 __device__ __forceinline__ float huber_rho(float r, float th) {
-  // w^2 with w = 1 inside the window, sqrt(2 b |r| - b^2)/|r| outside (utils.py:327-340)
+  // w^2 with w = 1 inside the window, sqrt(2 b |r| - b^2)/|r| outside (utils.py:327-340).  The reference evaluates
+  // sqrt(res_norm) / x AFTER replacing x == 0 by 1, with res_norm = x^2 = 0 there: a residual that is exactly zero gets
+  // weight 0 (its row drops out of H as well as of b) -- reproduced, golden vector G5.
   const float a = fabsf(r);
-  if (th <= 0.f || a <= th) return 1.f;
+  if (th <= 0.f) return 1.f;          // robust kernel off (before robust_iter, mask term)
+  if (a == 0.f) return 0.f;
+  if (a <= th) return 1.f;
   return (2.f * th * a - th * th) / (a * a);
 }
 

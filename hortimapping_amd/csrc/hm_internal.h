@@ -101,6 +101,10 @@ int launch_decoder_h(const hm_decoder_s* dec, int B, const float* d_pts, const i
                      int n_stride, const float* d_c0, const float* d_c4, float* d_y, float* d_J, int ldJ,
                      int pose_dim, int mode, hipStream_t stream, int tag);
 
+int launch_decoder_p(const hm_decoder_s* dec, int B, const float* d_pts, const int* d_nq, const int* d_active,
+                     int n_stride, const float* d_c0, const float* d_c4, float* d_y, float* d_J, int ldJ,
+                     int pose_dim, int mode, hipStream_t stream, int tag);
+
 int launch_normal_eq(const RowSegment* segs, int n_seg, int L, int B, const int* d_active, float* d_Hext,
                      hipStream_t stream);
 

@@ -214,7 +214,7 @@ extern "C" int hm_decoder_latent_dim(const hm_decoder_s* d) { return d ? d->L : 
 
 extern "C" int hm_decoder_set_precision(hm_decoder_s* d, int precision) {
   if (d == nullptr) { hm_set_error("null decoder"); return -1; }
-  if (precision != 0 && precision != 1) { hm_set_error("precision must be 0 (f32) or 1 (f16x3)"); return -1; }
+  if (precision < 0 || precision > 3) { hm_set_error("precision must be 0 (f32), 1 (f16x3), 2 (f16x3f_f16b) or 3 (f16)"); return -1; }
   d->precision = precision;
   return 0;
 }

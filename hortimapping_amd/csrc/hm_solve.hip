@@ -59,55 +59,89 @@ __device__ __forceinline__ float rdlane(float v, int l) {
 // Triangular solves L y = r, L^T x = y on the packed factor in LDS whose DIAGONAL 32x32 blocks have been replaced by
 // their inverses: every block step is a 32x32 mat-vec (no serial chain) plus a workgroup-wide off-diagonal update.
 // `rv` holds the right-hand side on entry and the solution on exit.
+// Latency structure: everything a phase needs from the FACTOR (which does not depend on rv) is fetched into registers
+// before the preceding barrier, so after the barrier a phase is eight broadcast reads of rv and 32 FMAs on four partial
+// sums -- not 64 dependent LDS round trips (the first version spent 6.5k cycles per block step that way).
+static_assert(MAX_E - 32 <= NT, "one off-diagonal row per thread");
 __device__ void solve_packed(const float* Lp, float* rv, int E, int tid, bool forward = true) {
-  const int lane = tid & 63, wv = tid >> 6;
+  const int lane = tid & 63, wv = tid >> 6, c = lane & 31;
   const int nblk = (E + 31) / 32;
   for (int bb = 0; forward && bb < nblk; ++bb) {           // forward
     const int base = bb * 32;
+    const int hi = (base + 32 < E) ? 32 : E - base;
+    float la[32], lb[32];
+    const int ia = base + c;                               // wave 0: row of the inverted diagonal block
     if (wv == 0) {
-      const int i = base + (lane & 31);
-      float s = 0.f;
-      if (i < E) {
-        const float* lr = Lp + tri(i, base);
-#pragma unroll 8
-        for (int k = 0; k < 32; ++k) s = fmaf((k <= (lane & 31)) ? lr[k] : 0.f, rv[base + k], s);
+      const float* lr = Lp + tri(ia < E ? ia : base, base);
+#pragma unroll
+      for (int k = 0; k < 32; ++k) la[k] = (ia < E && k <= c) ? lr[k] : 0.f;
+    }
+    const int ib = base + 32 + tid;                        // every thread: one row below the diagonal block
+    const bool rowb = ib < E;
+    if (rowb) {
+      const float* lr = Lp + tri(ib, base);
+#pragma unroll
+      for (int kk = 0; kk < 32; ++kk) lb[kk] = kk < hi ? lr[kk] : 0.f;
+    }
+    if (wv == 0) {
+      float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+      for (int k = 0; k < 32; k += 4) {
+        const f32x4 r4 = *reinterpret_cast<const f32x4*>(rv + base + k);
+        s0 = fmaf(la[k], r4[0], s0); s1 = fmaf(la[k + 1], r4[1], s1);
+        s2 = fmaf(la[k + 2], r4[2], s2); s3 = fmaf(la[k + 3], r4[3], s3);
       }
       __builtin_amdgcn_wave_barrier();
-      if (lane < 32 && i < E) rv[i] = s;
+      if (lane < 32 && ia < E) rv[ia] = (s0 + s1) + (s2 + s3);
     }
     __syncthreads();
-    const int hi = (base + 32 < E) ? 32 : E - base;
-    for (int i = base + 32 + tid; i < E; i += NT) {
-      float s = 0.f;
-      const float* lr = Lp + tri(i, base);
-#pragma unroll 8
-      for (int kk = 0; kk < 32; ++kk) s = fmaf(kk < hi ? lr[kk] : 0.f, rv[base + (kk < hi ? kk : 0)], s);
-      rv[i] -= s;
+    if (rowb) {
+      float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+      for (int k = 0; k < 32; k += 4) {
+        const f32x4 r4 = *reinterpret_cast<const f32x4*>(rv + base + k);
+        s0 = fmaf(lb[k], r4[0], s0); s1 = fmaf(lb[k + 1], r4[1], s1);
+        s2 = fmaf(lb[k + 2], r4[2], s2); s3 = fmaf(lb[k + 3], r4[3], s3);
+      }
+      rv[ib] -= (s0 + s1) + (s2 + s3);
     }
     __syncthreads();
   }
   for (int bb = nblk - 1; bb >= 0; --bb) {                 // backward (transposed)
     const int base = bb * 32;
     const int hi = (base + 32 < E) ? 32 : E - base;
+    float la[32], lb[32];
+    const int ja = base + c;                               // wave 0: column of the inverted diagonal block
     if (wv == 0) {
-      const int j = base + (lane & 31);
-      float s = 0.f;
-      if (j < E) {
-#pragma unroll 8
-        for (int ii = 0; ii < 32; ++ii) {
-          const bool use = ii >= (lane & 31) && ii < hi;
-          s = fmaf(use ? Lp[tri(base + ii, j)] : 0.f, rv[base + (ii < hi ? ii : 0)], s);
-        }
+#pragma unroll
+      for (int ii = 0; ii < 32; ++ii) la[ii] = (ja < E && ii >= c && ii < hi) ? Lp[tri(base + ii, ja)] : 0.f;
+    }
+    const bool colb = tid < base;                          // every thread: one column left of the diagonal block
+    if (colb) {
+#pragma unroll
+      for (int ii = 0; ii < 32; ++ii) lb[ii] = ii < hi ? Lp[tri(base + ii, tid)] : 0.f;
+    }
+    if (wv == 0) {
+      float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+      for (int k = 0; k < 32; k += 4) {
+        const f32x4 r4 = *reinterpret_cast<const f32x4*>(rv + base + k);
+        s0 = fmaf(la[k], r4[0], s0); s1 = fmaf(la[k + 1], r4[1], s1);
+        s2 = fmaf(la[k + 2], r4[2], s2); s3 = fmaf(la[k + 3], r4[3], s3);
       }
       __builtin_amdgcn_wave_barrier();
-      if (lane < 32 && j < E) rv[j] = s;
+      if (lane < 32 && ja < E) rv[ja] = (s0 + s1) + (s2 + s3);
     }
     __syncthreads();
-    for (int j = tid; j < base; j += NT) {
-      float s = 0.f;
-#pragma unroll 8
-      for (int ii = 0; ii < 32; ++ii) s = fmaf(ii < hi ? Lp[tri(base + (ii < hi ? ii : 0), j)] : 0.f, rv[base + (ii < hi ? ii : 0)], s);
-      rv[j] -= s;
+    if (colb) {
+      float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+      for (int k = 0; k < 32; k += 4) {
+        const f32x4 r4 = *reinterpret_cast<const f32x4*>(rv + base + k);
+        s0 = fmaf(lb[k], r4[0], s0); s1 = fmaf(lb[k + 1], r4[1], s1);
+        s2 = fmaf(lb[k + 2], r4[2], s2); s3 = fmaf(lb[k + 3], r4[3], s3);
+      }
+      rv[tid] -= (s0 + s1) + (s2 + s3);
     }
     __syncthreads();
   }
@@ -120,7 +154,7 @@ __global__ __launch_bounds__(NT) void k_solve_update(const SolveArgs a) {
   __shared__ float smem[MAX_E * (MAX_E + 1) / 2];
   __shared__ float bvec[NBK * 32];
   __shared__ float xvec[NBK * 32];
-  __shared__ float rv[NBK * 32];
+  __shared__ __attribute__((aligned(16))) float rv[NBK * 32];
   __shared__ float diagA[NBK * 32];
   __shared__ double cs[NBK * 32], rs[NBK * 32];   // fp64 column / row sums of the refinement residual
   __shared__ __attribute__((aligned(16))) float colk[32];
@@ -224,6 +258,8 @@ __global__ __launch_bounds__(NT) void k_solve_update(const SolveArgs a) {
   }
   float* Pn = smem;                                             // panel: Pn[(bi * 32 + row) * PS + col]
   for (int bj = 0; bj < nblk; ++bj) {
+    const bool trj = trc && bj == 0;          // phase stamps of the first (largest) block column
+    if (trj) g_k5_trace[8] = clock64();
     // 1. owners of block column bj publish their blocks
 #pragma unroll
     for (int sl = 0; sl < NSLOT; ++sl)
@@ -233,6 +269,7 @@ __global__ __launch_bounds__(NT) void k_solve_update(const SolveArgs a) {
           Pn[(obi[sl] * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh) * PS + cc] = blk[sl][r];
       }
     __syncthreads();
+    if (trj) g_k5_trace[9] = clock64();
     // 2. diagonal block: in-wave Cholesky, lane = row, columns in registers, broadcasts by v_readlane
     if (wv == 0) {
       float ar[32];
@@ -268,7 +305,9 @@ __global__ __launch_bounds__(NT) void k_solve_update(const SolveArgs a) {
         for (int k = 0; k < 32; ++k) dst[k] = (k <= cc) ? ar[k] : 0.f;
       }
     }
+    if (trj) g_k5_trace[10] = clock64();
     __syncthreads();
+    if (trj) g_k5_trace[11] = clock64();
     // 3. panel below the diagonal block: row-wise forward substitution  x L11^T = a
     {
       const int nrow = (nblk - 1 - bj) * 32;
@@ -290,7 +329,9 @@ __global__ __launch_bounds__(NT) void k_solve_update(const SolveArgs a) {
         for (int k = 0; k < 32; ++k) row[k] = x[k];
       }
     }
+    if (trj) g_k5_trace[12] = clock64();
     __syncthreads();
+    if (trj) g_k5_trace[13] = clock64();
     // 4. trailing update  A22 -= L21 L21^T  on the matrix cores, and the finished panel goes to global scratch
 #pragma unroll
     for (int sl = 0; sl < NSLOT; ++sl)
@@ -313,7 +354,9 @@ __global__ __launch_bounds__(NT) void k_solve_update(const SolveArgs a) {
         Lg[(size_t)(bj * 32 + r) * LGS + bj * 32 + k] = Pn[(bj * 32 + r) * PS + k];
       }
     }
+    if (trj) g_k5_trace[14] = clock64();
     __syncthreads();
+    if (trj) g_k5_trace[15] = clock64();
   }
   if (flag) {
     if (tid == 0) { a.active[b] = 0; a.status[b] |= HM_STATUS_SOLVE_FAILED; }
@@ -333,18 +376,35 @@ __global__ __launch_bounds__(NT) void k_solve_update(const SolveArgs a) {
     if (bb < nblk) {
       const int base = bb * 32;
       float x[32];
+      // row k of L11 (k + 1 broadcast reads) is fetched one row AHEAD of its use: the forward substitution then costs
+      // one LDS latency per row overlapped with the previous row's dot product, instead of a round trip per element
+      float cur[32], nxt[32];
+      {
+        const float* lr = Lp + tri(base, base);
+        cur[0] = lr[0];
+      }
 #pragma unroll
       for (int k = 0; k < 32; ++k) {
         const int i = base + k;
-        float sacc = (k == cc) ? 1.f : 0.f;
-        if (i < E) {
+        if (k + 1 < 32) {
+          const int in = i + 1 < E ? i + 1 : base;               // rows past E are never used (x stays 0)
+          const float* lr = Lp + tri(in, base);
 #pragma unroll
-          for (int m2 = 0; m2 < k; ++m2) sacc = fmaf(-x[m2], Lp[tri(i, base + m2)], sacc);
-          x[k] = (k >= cc) ? sacc / Lp[tri(i, i)] : 0.f;
-        } else {
-          x[k] = 0.f;
+          for (int m2 = 0; m2 <= k + 1; ++m2) nxt[m2] = lr[m2];
         }
         __builtin_amdgcn_sched_barrier(0);
+        float s0 = (k == cc) ? 1.f : 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+        for (int m2 = 0; m2 < k; ++m2) {
+          if ((m2 & 3) == 0) s0 = fmaf(-x[m2], cur[m2], s0);
+          else if ((m2 & 3) == 1) s1 = fmaf(-x[m2], cur[m2], s1);
+          else if ((m2 & 3) == 2) s2 = fmaf(-x[m2], cur[m2], s2);
+          else s3 = fmaf(-x[m2], cur[m2], s3);
+        }
+        x[k] = (i < E && k >= cc) ? ((s0 + s1) + (s2 + s3)) / cur[k] : 0.f;
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m2 = 0; m2 <= k + 1 && m2 < 32; ++m2) cur[m2] = nxt[m2];
       }
       __builtin_amdgcn_wave_barrier();
 #pragma unroll

@@ -71,17 +71,19 @@ class DecoderWeights:
         if default:
             self.set_precision(default)
 
-    PRECISIONS = {"f32": 0, "f16x3": 1}
+    PRECISIONS = {"f32": 0, "f16x3": 1, "f16x3f_f16b": 2, "f16": 3}
 
     def set_precision(self, name: str):
-        """'f32' (exact fp32 MFMA, default) or 'f16x3' (fp16 MFMA, hi/lo split operands, ~2^-22 relative)."""
+        """'f32' (exact fp32 MFMA, default), 'f16x3' (fp16 MFMA, hi/lo split operands, ~2^-22 relative) or the
+        mixed 'f16x3f_f16b' (forward as f16x3, backward in one fp16 pass: Jacobians ~1e-3 relative, NOT fp32-class) or
+        'f16' (plain fp16 MFMA decoder of BASELINE.json configs[4]: everything ~1e-3 relative)."""
         _lib.check(_lib.lib().hm_decoder_set_precision(self.handle, self.PRECISIONS[name]), "hm_decoder_set_precision")
         return self
 
     @property
     def precision(self) -> str:
         v = _lib.lib().hm_decoder_get_precision(self.handle)
-        return {0: "f32", 1: "f16x3"}[v]
+        return {v_: k for k, v_ in self.PRECISIONS.items()}[v]
 
     @classmethod
     def from_params(cls, params):

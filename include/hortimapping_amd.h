@@ -55,7 +55,14 @@ int hm_decoder_latent_dim(hm_decoder_t dec);
  *      ~2^-22 relative accuracy (fp32 class), 16/3 x the MFMA rate.  Hidden activations and back-propagated
  *      gradients are held as fp16 hi/lo pairs, so they must stay below 65504 in magnitude; a 64-query tile that
  *      exceeds it returns NaN sdf / Jacobian rows (never silent garbage) and hm_optimize_batch ends that instance
- *      with HM_STATUS_SOLVE_FAILED.  Mode 0 has no such limit. */
+ *      with HM_STATUS_SOLVE_FAILED.  Mode 0 has no such limit.
+ *   2  "f16x3f_f16b" (mixed, NOT fp32-class; BASELINE.json configs[4] "fp16 MFMA decoder"): the forward stages --
+ *      residuals, ReLU masks, sdf -- as mode 1, the eight input-gradient (backward) stages in ONE fp16 MFMA pass on the
+ *      hi parts: 4 instead of 6 matrix passes per query; Jacobian rows carry ~2^-11 relative rounding per layer.
+ *   3  "f16" (plain fp16 MFMA decoder, NOT fp32-class): one fp16 pass for every product, fp16 activations, fp32
+ *      accumulation; 128-query tiles (the single activation plane of 128 queries fills the LDS), so each weight byte
+ *      serves twice as many queries and only the hi plane is streamed.  sdf, residuals AND Jacobians are fp16-class
+ *      (~1e-3 relative); ReLU / occupancy / with-grad decisions can differ from the reference's. */
 int hm_decoder_set_precision(hm_decoder_t dec, int precision);
 int hm_decoder_get_precision(hm_decoder_t dec);
 
@@ -175,7 +182,7 @@ int hm_render_residuals(hm_workspace_t ws, const hm_opt_cfg* cfg, const hm_batch
 /* ---- performance-analysis aids (not part of the drop-in surface): when a device buffer is registered, block 0 of
  * the f16x3 decoder kernel / of the solve kernel writes shader-clock stamps per stage into it (scripts/gpu_trace_*.py). */
 void hm_debug_set_trace(long long* d_buf);      /* [NSTAGE * 4 + 1] or NULL */
-void hm_debug_set_k5_trace(long long* d_buf);   /* [6] or NULL */
+void hm_debug_set_k5_trace(long long* d_buf);   /* [16] or NULL */
 
 /* ---- unit hooks (tests): the device functions of the solve kernel / normal-equation kernel on caller-supplied values.
  * hm_debug_exp_map replaces exp_sim3 (sim3 != 0; wild_completion/utils.py:279-324) / exp_se3 (:220-254) for n tangents

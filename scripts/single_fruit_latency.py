@@ -1,0 +1,34 @@
+"""Wall time of ONE drop-in `Optimizer.shape_pose_joint_opt` call per fruit -- the reference's usage pattern
+(test_wild_completion.py:224: one call per submap; README.md:23 quotes 0.6 s per fruit on an unnamed CUDA GPU) -- at
+wild_pepper.yaml sizes (L = 32, Sim(3), 10 frames x 400 rays x 30 samples, 2000 points, early exits on).
+The first call pays the workspace allocation; later calls reuse it (grow-only cache on the Optimizer)."""
+import os, sys, time, json
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch, yaml
+from hortimapping_amd import synthetic as S, workloads as W
+from hortimapping_amd.decoder import DecoderWeights
+from hortimapping_amd.optimizer import Optimizer
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+cfg = yaml.safe_load(open(os.path.join(ROOT, "configs", "wild_pepper.yaml")))
+cfg["vis"]["log_on"] = False
+p = S.make_synthetic_decoder(32, seed=1, r0=0.04, aniso=(1.0, 0.75, 1.3))
+Ws, bs = S.fold_weight_norm(p)
+out = {}
+for prec in ("f32", "f16x3"):
+    dec = DecoderWeights.from_params(p); dec.set_precision(prec)
+    fac = W.gpu_sdf_factory(dec)
+    protos = [S.make_instance(Ws, bs, 32, i, sdf_fn_factory=fac, n_pts=2000, n_frames=10, n_fg=200, n_bg=200) for i in range(6)]
+    opt = Optimizer(cfg, dec, None, None)
+    times, iters = [], []
+    for rep in range(3):
+        for d in protos:
+            inst = W.to_instance(d)
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            z, T, n = opt.shape_pose_joint_opt(inst.latent.clone(), inst.T_ow, inst.render_data, inst.points_w,
+                                               inst.cube_radius, None)
+            torch.cuda.synchronize(); times.append(time.perf_counter() - t0); iters.append(n)
+    first, rest = times[0], np.array(times[1:])
+    out[prec] = {"first_call_ms": round(1e3 * first, 1), "later_calls_ms_median": round(1e3 * float(np.median(rest)), 1),
+                 "later_calls_ms_min_max": [round(1e3 * float(rest.min()), 1), round(1e3 * float(rest.max()), 1)],
+                 "iterations_mean": float(np.mean(iters)), "workspace_MiB": round(opt._cache["ws"].nbytes / 2**20, 1)}
+print(json.dumps({"single_fruit_latency": out, "reference_quote": "0.6 s per fruit (README.md:23, unnamed CUDA GPU)"}))

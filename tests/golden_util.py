@@ -57,3 +57,27 @@ def relmax(a, b, floor=1e-30):
     a = np.asarray(a, dtype=np.float64)
     b = np.asarray(b, dtype=np.float64)
     return float(np.abs(a - b).max() / max(np.abs(b).max(), floor))
+
+
+PRECISIONS = ["f32", "f16x3", "f16x3f_f16b"]       # decoder arithmetics every parametrised GPU test module runs in
+
+
+def precision():
+    return os.environ.get("HM_PRECISION", "f32")
+
+
+def T(fp32_class, mixed):
+    """Tolerance selector: `fp32_class` for the two fp32-class arithmetics (exact f32, f16x3), `mixed` for
+    'f16x3f_f16b', whose backward (Jacobian) stages run ONE fp16 pass: forward quantities (sdf, residuals, ReLU
+    decisions) keep the fp32-class bound, anything that goes through a Jacobian is held to ~1e-3 instead."""
+    return mixed if precision() == "f16x3f_f16b" else fp32_class
+
+
+def traj_noise(tag):
+    """(latent, T_ow, iter_count) deviation of the REFERENCE loop itself under a 1e-7 relative perturbation of the
+    surface points (fixture g16, made by make_golden_r2.py from the imported reference): max over the two signs."""
+    g = load("g16_traj_noise")
+    if tag not in g.files:
+        return 0.0, 0.0, 0.0
+    a = np.abs(g[tag])
+    return float(a[:, 0].max()), float(a[:, 1].max()), float(a[:, 2].max())

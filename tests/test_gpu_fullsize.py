@@ -1,6 +1,7 @@
 """GPU tests at BASELINE.json's full sizes (64 instances, 256-dim latent, 8x512 decoder, 2048 decoder points per
-iteration) through size-independent properties, plus metric-level parity (Chamfer / pose error) against the oracle
-on a sample of the batch.  The iteration count is reduced so the whole file runs in about a minute."""
+iteration): size-independent properties (determinism, permutation equivariance, frozen-after-exit) and metric-level
+parity (Chamfer-to-ground-truth / pose error) of ALL 64 instances after the full 200 iterations against committed
+CPU-oracle records."""
 import numpy as np
 import pytest
 import torch
@@ -9,10 +10,9 @@ pytestmark = pytest.mark.gpu
 
 L, B = 256, 64
 _S = {}
-_ORACLE = {}      # CPU oracle results, shared by the two precision parametrisations
 
 
-@pytest.fixture(params=["f32", "f16x3"], autouse=True, scope="module")
+@pytest.fixture(params=["f32", "f16x3", "f16x3f_f16b", "f16"], autouse=True, scope="module")
 def precision(request):
     import os
     os.environ["HM_PRECISION"] = request.param
@@ -56,9 +56,11 @@ def test_fullsize_deterministic_and_permutation_equivariant():
         assert torch.equal(r3[k].latent, r1[i].latent) and torch.equal(r3[k].T_ow, r1[i].T_ow)      # order only relabels
 
 
-def test_fullsize_frozen_after_exit():
+def test_fullsize_frozen_after_exit(precision):
     """An instance that converges is frozen bit-exactly: running more iterations does not change it."""
     from hortimapping_amd import workloads as W
+    if precision == "f16":
+        pytest.skip("fp16-class arithmetic: the 3e-4 gradient threshold of this test is below its noise")
     s = setup()
     insts = [W.to_instance(d) for d in s["dicts"][:8]]
     cfg_a = W.c2_opt_cfg(max_iter=12)
@@ -75,54 +77,128 @@ def test_fullsize_frozen_after_exit():
     assert n_conv > 0
 
 
-@pytest.mark.parametrize("pose_known", [True, False])
-def test_fullsize_metric_parity_vs_oracle(pose_known):
-    """Chamfer-to-ground-truth and pose error of the HIP result vs the CPU oracle's result on the same inputs
-    (two instances of the batch, 20 LM iterations).  BASELINE.json asks for 1e-4 relative: pose_known runs are held
-    to it.  Free-pose runs are chaotic (hard with_grad / ball / Huber / ReLU switches amplify rounding noise, SURVEY.md
-    8d): two fp32 evaluations of the REFERENCE ALGORITHM ITSELF (the oracle vs the oracle with the surface points
-    scaled by 1 + 1e-7) differ by 3e-4 ... 1e-2 in Chamfer-to-GT at these sizes (scripts/parity_fullsize.py, DESIGN.md
-    section 2), and which instance flips is perturbation dependent.  The free-pose bar is therefore that band (2e-2),
-    or 5x the noise measured in this very test if that is larger."""
-    from hortimapping_amd import metrics as MX, utils as U, workloads as W
-    from oracle import hm_oracle as O
-    s = setup()
-    n_it = 20
-    cfg = W.c2_opt_cfg(max_iter=n_it)
-    pick = [3, 41]
-    insts = [W.to_instance(s["dicts"][i], pose_known=pose_known) for i in range(B)]
-    res = run(insts, cfg)
-    od = O.fold_decoder(s["params"])
-    dec = s["dec"]
+# ----------------------------------------------------------------------------------------------------------------
+# Full-batch metric parity at BASELINE.json's size: ALL 64 instances x 200 LM iterations, both pose modes, every
+# decoder arithmetic, against CPU-oracle records committed as fixtures (tests/golden/make_fullsize_records.py: the
+# oracle on the nominal inputs and on four 1e-7-relative input perturbations, 640 runs, ~45 min on 8 cores).
+# ----------------------------------------------------------------------------------------------------------------
+K_NOISE = 3.0          # a GPU result may sit K_NOISE x further from the oracle than the oracle's own perturbed runs
+REL_FLOOR = 1e-4       # BASELINE.json north_star: "Chamfer distance / pose error within 1e-4 relative"
+_FS = {}
 
-    def pts(latent, T_ow):
-        return MX.completed_points_world(lambda p: U.decode_sdf(dec, latent, torch.from_numpy(p)).cpu().numpy(),
-                                         T_ow.numpy())
-    for i in pick:
-        d = s["dicts"][i]
-        rd = {k: [torch.from_numpy(a) for a in v] for k, v in d["render"].items()}
-        args = (od, cfg, torch.from_numpy(d["latent0"]), torch.from_numpy(d["T_ow0"]), rd)
-        if (i, pose_known) not in _ORACLE:
-            a = O.shape_pose_joint_opt(*args, torch.from_numpy(d["points_w"]), d["cube_radius"], pose_known=pose_known)
-            b2 = O.shape_pose_joint_opt(*args, torch.from_numpy(d["points_w"]) * (1 + 1e-7), d["cube_radius"],
-                                        pose_known=pose_known)
-            _ORACLE[(i, pose_known)] = (a, b2)
-        (z, T, n), (z2, T2, _) = _ORACLE[(i, pose_known)]
-        assert res[i].iter_count == n == n_it
-        gt = pts(torch.from_numpy(d["z_true"]), torch.from_numpy(np.linalg.inv(d["T_wo_true"]).astype(np.float32)))
-        cd_gpu = MX.chamfer_distance(pts(res[i].latent, res[i].T_ow), gt)
-        cd_cpu = MX.chamfer_distance(pts(z, T), gt)
-        cd_cpu2 = MX.chamfer_distance(pts(z2, T2), gt)
-        rel = abs(cd_gpu - cd_cpu) / cd_cpu
-        noise = abs(cd_cpu2 - cd_cpu) / cd_cpu
-        pe_g, pe_c = MX.pose_error(res[i].T_ow.numpy(), d["T_wo_true"]), MX.pose_error(T.numpy(), d["T_wo_true"])
-        pe_c2 = MX.pose_error(T2.numpy(), d["T_wo_true"])
-        if pose_known:
-            tol_cd, tol_t, tol_s = 1e-4, 1e-4 * max(pe_c[0], 1e-3), 1e-4
-        else:
-            tol_cd = max(2e-2, 5 * noise)
-            tol_t = max(2e-2 * max(pe_c[0], 1e-3), 5 * abs(pe_c2[0] - pe_c[0]))
-            tol_s = max(2e-2, 5 * abs(pe_c2[2] - pe_c[2]))
-        assert rel < tol_cd, (rel, noise, cd_gpu, cd_cpu)
-        assert abs(pe_g[0] - pe_c[0]) < tol_t
-        assert abs(pe_g[2] - pe_c[2]) < tol_s
+
+def fullsize_fixture():
+    """Inputs, oracle records and the per-instance metrics of the oracle runs (computed once per session with ONE
+    sampler for every party: the exact-fp32 GPU decoder along 2000 Fibonacci directions, metrics.py)."""
+    if _FS:
+        return _FS
+    import os
+    from hortimapping_amd import metrics as MX, ops, synthetic as S
+    from hortimapping_amd.decoder import DecoderWeights
+    from golden_util import GOLDEN_DIR
+    inp = np.load(os.path.join(GOLDEN_DIR, "c2_fullsize_inputs.npz"))
+    rec = np.load(os.path.join(GOLDEN_DIR, "c2_fullsize_oracle.npz"))
+    params = S.make_synthetic_decoder(L, seed=2, r0=0.04, aniso=(1.0, 0.75, 1.3))
+    sampler = DecoderWeights.from_params(params)
+    sampler.set_precision("f32")
+    dirs = torch.from_numpy(MX.fibonacci_dirs(2000)).float().cuda()
+
+    def level_sets(latents):
+        """(n, 2000, 3) object-frame zero-level-set points of n shapes: bisection along fixed rays, batched."""
+        lat = torch.as_tensor(latents, dtype=torch.float32).cuda().contiguous()
+        n = lat.shape[0]
+        lo = torch.zeros(n, 2000, device="cuda")
+        hi = torch.full((n, 2000), 0.08, device="cuda")
+        nq = torch.full((n,), 2000, dtype=torch.int32, device="cuda")
+        pts4 = torch.zeros(n, 2048, 4, device="cuda")
+        for _ in range(24):
+            mid = 0.5 * (lo + hi)
+            pts4[:, :2000, :3] = dirs[None] * mid[..., None]
+            y, _ = ops.decode_batch(sampler, lat, pts4, nq, mode=0)
+            inside = y[:, :2000] < 0
+            lo = torch.where(inside, mid, lo)
+            hi = torch.where(inside, hi, mid)
+        return (dirs[None] * (0.5 * (lo + hi))[..., None]).double().cpu().numpy()
+
+    def metrics(latents, T_ows):
+        """per instance: (Chamfer-to-GT [m], translation error [m], rotation error [deg], scale ratio)"""
+        P = level_sets(latents)
+        out = np.zeros((len(latents), 4))
+        for i in range(len(latents)):
+            T_wo = np.linalg.inv(np.asarray(T_ows[i], dtype=np.float64))
+            pw = P[i] @ T_wo[:3, :3].T + T_wo[:3, 3]
+            out[i, 0] = MX.chamfer_distance(pw, _FS["gt"][i])
+            out[i, 1:] = MX.pose_error(np.asarray(T_ows[i]), inp["T_wo_true"][i])
+        return out
+    n = inp["latent0"].shape[0]
+    Pgt = level_sets(inp["z_true"])
+    _FS["gt"] = [Pgt[i] @ inp["T_wo_true"][i][:3, :3].astype(np.float64).T + inp["T_wo_true"][i][:3, 3] for i in range(n)]
+    _FS.update(inp=inp, rec=rec, metrics=metrics, n=n, params=params, oracle={})
+    for mode in ("known", "free"):
+        _FS["oracle"][mode] = np.stack([metrics(rec[f"{mode}_latent"][p], rec[f"{mode}_T_ow"][p])
+                                        for p in range(rec[f"{mode}_latent"].shape[0])])     # (perts, n, 4)
+    return _FS
+
+
+def fullsize_instances(pose_known):
+    from hortimapping_amd import optimizer as HO
+    inp = fullsize_fixture()["inp"]
+    t = torch.from_numpy
+    return [HO.Instance(t(inp["latent0"][i].copy()), t(inp["T_ow0"][i].copy()), t(inp["points_w"][i]),
+                        {"T_wc": [t(inp["T_wc"][i])], "rays_fg": [t(inp["rays_fg"][i])], "rays_bg": [t(inp["rays_bg"][i])],
+                         "depth_fg": [t(inp["depth_fg"][i])], "depth_bg": [t(inp["depth_bg"][i])]},
+                        float(inp["cube_radius"][i]), pose_known) for i in range(inp["latent0"].shape[0])]
+
+
+@pytest.mark.parametrize("mode", ["known", "free"])
+def test_full_batch_metric_parity(mode, precision):
+    """For EVERY one of the 64 c2_joint instances after 200 iterations:
+        |m_gpu - m_cpu| <= max(1e-4 * scale(m_cpu), K_NOISE * noise_i)        m = Chamfer-to-GT, pose errors
+    with noise_i = the largest deviation of the four perturbed oracle runs of instance i from its nominal run (the
+    reference algorithm's own response to a 1e-7 relative input change).  The two fp32-class arithmetics (f32, f16x3)
+    must pass on all 64; failures are listed by instance id.  The per-instance table is written to
+    gpurun_out/r02_parity_fullsize_<mode>_<precision>.txt (copied to profiles/)."""
+    import os
+    from hortimapping_amd import optimizer as HO, workloads as W
+    from hortimapping_amd.decoder import DecoderWeights
+    fs = fullsize_fixture()
+    n = fs["n"]
+    n_iter = int(fs["rec"]["n_iter"])
+    dec = DecoderWeights.from_params(fs["params"])
+    dec.set_precision(precision)
+    res = HO.optimize_batch(dec, W.c2_opt_cfg(max_iter=n_iter), fullsize_instances(mode == "known"))
+    assert all(r.iter_count == n_iter and r.status == 8 for r in res)
+    assert np.array_equal(fs["rec"][f"{mode}_iter_count"], np.full_like(fs["rec"][f"{mode}_iter_count"], n_iter))
+    m_gpu = fs["metrics"](torch.stack([r.latent for r in res]).numpy(), [r.T_ow.numpy() for r in res])
+    m_all = fs["oracle"][mode]
+    m_cpu, m_pert = m_all[0], m_all[1:]
+    noise = np.abs(m_pert - m_cpu[None]).max(axis=0)                       # (n, 4)
+    scale = np.stack([m_cpu[:, 0], np.maximum(m_cpu[:, 1], 1e-3), np.maximum(m_cpu[:, 2], 0.1),
+                      np.ones(n)], axis=1)                                 # floors: 1 mm, 0.1 deg, unit scale ratio
+    tol = np.maximum(REL_FLOOR * scale, K_NOISE * noise)
+    dev = np.abs(m_gpu - m_cpu)
+    names = ("chamfer", "t_err", "r_err", "scale")
+    lines = [f"# c2_joint full batch, {n} instances x {n_iter} LM iterations, pose_{mode}, GPU {precision} vs CPU oracle",
+             f"# tolerance per instance and metric: max({REL_FLOOR:g} * scale, {K_NOISE:g} * noise_i); noise_i = max deviation "
+             "of 4 perturbed oracle runs (points x(1+-1e-7), T_ow0 x(1+1e-7), depth_fg x(1+1e-7))",
+             "# id  CD_cpu[mm]  CD_gpu[mm]  relCD_gpu  relCD_noise  dT[mm] noise_T[mm]  dR[deg] noise_R[deg]  dS noise_S  verdict"]
+    bad = []
+    for i in range(n):
+        ok = bool((dev[i] <= tol[i]).all())
+        if not ok:
+            bad.append((i, [names[k] for k in range(4) if dev[i, k] > tol[i, k]]))
+        lines.append(f"{i:3d} {1e3 * m_cpu[i, 0]:10.5f} {1e3 * m_gpu[i, 0]:10.5f} {dev[i, 0] / m_cpu[i, 0]:9.2e} "
+                     f"{noise[i, 0] / m_cpu[i, 0]:9.2e} {1e3 * dev[i, 1]:9.2e} {1e3 * noise[i, 1]:9.2e} {dev[i, 2]:9.2e} "
+                     f"{noise[i, 2]:9.2e} {dev[i, 3]:9.2e} {noise[i, 3]:9.2e}  {'ok' if ok else 'FAIL'}")
+    relcd, relnoise = dev[:, 0] / m_cpu[:, 0], noise[:, 0] / m_cpu[:, 0]
+    lines.append(f"# relative Chamfer-to-GT difference vs the oracle: median {np.median(relcd):.2e} p90 "
+                 f"{np.percentile(relcd, 90):.2e} max {relcd.max():.2e};  oracle perturbation noise: median "
+                 f"{np.median(relnoise):.2e} p90 {np.percentile(relnoise, 90):.2e} max {relnoise.max():.2e}")
+    lines.append(f"# instances within 1e-4 relative Chamfer outright: {(relcd <= 1e-4).sum()} of {n}; failing the gate: "
+                 f"{[b[0] for b in bad]}")
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open(os.path.join("gpurun_out", f"r02_parity_fullsize_{mode}_{precision}.txt"), "w") as f:
+        f.write("\n".join(lines) + "\n")
+    print("\n".join(lines[-2:]))
+    if precision in ("f32", "f16x3"):          # the fp32-class arithmetics are gated; the mixed mode is reported
+        assert not bad, f"{precision} pose_{mode}: instances outside max(1e-4, {K_NOISE} x noise): {bad}"

@@ -6,12 +6,13 @@ import os
 import pytest
 import torch
 
+from golden_util import PRECISIONS, T as TOL
 from test_gpu_configs import make, oracle_run, rel
 
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=["f32", "f16x3"], autouse=True, scope="module")
+@pytest.fixture(params=PRECISIONS, autouse=True, scope="module")
 def precision(request):
     os.environ["HM_PRECISION"] = request.param
     yield request.param
@@ -34,7 +35,7 @@ def test_max_samples_and_ragged_batch_vs_oracle():
         assert torch.equal(r.latent, s.latent) and torch.equal(r.T_ow, s.T_ow)      # padding-independent, bit for bit
         z, T, n = oracle_run(od, opt, d, True, ("lim", j))
         assert r.iter_count == n == 4
-        assert rel(r.latent, z) < 2e-3 and rel(r.T_ow, T) < 1e-4
+        assert rel(r.latent, z) < TOL(2e-3, 5e-2) and rel(r.T_ow, T) < TOL(1e-4, 3e-3)
 
 
 def test_requests_beyond_the_workspace_limits_fail_loudly():
@@ -76,7 +77,7 @@ def test_frame_without_enough_ball_samples_is_skipped_like_the_reference():
     for j, (r, d) in enumerate(zip(res, dicts)):
         z, T, n = oracle_run(od, opt, d, True, ("skipframe", j))
         assert r.iter_count == n == 4 and r.status == (8 | 64 if j == 0 else 8)     # 64 = HM_STATUS_FRAME_SKIPPED
-        assert rel(r.latent, z) < 2e-3 and rel(r.T_ow, T) < 1e-4
+        assert rel(r.latent, z) < TOL(2e-3, 5e-2) and rel(r.T_ow, T) < TOL(1e-4, 3e-3)
     assert int(counts[0, 0]) < int(counts[1, 0])         # the skipped frame's samples are not counted for instance 0
 
 

@@ -14,8 +14,8 @@ import numpy as np
 import pytest
 import torch
 
-from tests.golden_util import (cfg_from_golden, decoder_params, list_golden, load, relmax,
-                               render_data_from_golden)
+from tests.golden_util import (PRECISIONS, T, cfg_from_golden, decoder_params, list_golden, load, relmax,
+                               render_data_from_golden, traj_noise)
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -23,10 +23,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 _CACHE = {}
 
 
-@pytest.fixture(params=["f32", "f16x3"], autouse=True, scope="module")
+@pytest.fixture(params=PRECISIONS, autouse=True, scope="module")
 def precision(request):
-    """Every test of this module runs for both decoder arithmetics: exact fp32 MFMA and the fp16 split-operand
-    (f16x3) MFMA path; the tolerances are the same for both."""
+    """Every test of this module runs for all decoder arithmetics: exact fp32 MFMA and the fp16 split-operand
+    (f16x3) MFMA path with the SAME tolerances, and the mixed f16x3-forward / fp16-backward mode with the looser
+    Jacobian-side tolerances `T(fp32_class, mixed)` states next to each assertion."""
     import os
     os.environ["HM_PRECISION"] = request.param
     _CACHE.clear()
@@ -65,7 +66,7 @@ def test_decoder_vs_golden(name):
     y, jac = U.get_batch_sdf_jacobian(dec, z, x)
     assert y.shape == (64, 1, 1) and jac.shape == (64, 1, g["g"].shape[1])
     assert relmax(y.cpu().reshape(-1), g["y"]) < 5e-6
-    assert relmax(jac.cpu()[:, 0], g["g"]) < 1e-5
+    assert relmax(jac.cpu()[:, 0], g["g"]) < T(1e-5, 2e-3)
 
 
 @pytest.mark.parametrize("L", [32, 64, 128, 256])
@@ -95,13 +96,13 @@ def test_decoder_vs_fp64_oracle_ragged(L):
             yo, go = O.decoder_jacobian(od, lat[b], pts[b, :k])
             # natural scales: sdf ~ r0 = 0.04, d sdf/d z ~ 1e-2, d sdf/d x ~ 1
             assert relmax(y[b, :k], yo, 0.04) < 5e-6
-            assert relmax(J[b, :k, :L], go[:, :L], 0.01) < 1e-5
+            assert relmax(J[b, :k, :L], go[:, :L], 0.01) < T(1e-5, 2e-3)
             assert relmax(J[b, :k, L + 7], yo, 0.04) < 5e-6           # residual column of the extended row
             if pose_dim == 0:
                 ref = go[:, L:]
             else:
                 ref = torch.einsum("ni,nip->np", go[:, L:], O.pose_jacobian(pts[b, :k].double(), pose_dim == 7))
-            assert relmax(J[b, :k, L:L + ref.shape[1]], ref, 0.1) < 1e-5
+            assert relmax(J[b, :k, L:L + ref.shape[1]], ref, 0.1) < T(1e-5, 2e-3)
             assert float(J[b, k:].abs().max()) == 0.0                 # rows beyond n_q untouched
 
 
@@ -115,8 +116,8 @@ def test_sdf_loss_vs_golden(name):
         res, jp, jc = HL.compute_sdf_loss(dec, torch.from_numpy(g["z"]), torch.from_numpy(g["pts_o"]), so)
         assert res.shape[1:] == (1, 1) and jp.shape[1:] == (1, 7 if so else 6)
         assert relmax(res.cpu().reshape(-1), g[f"res_{sfx}"]) < 5e-6
-        assert relmax(jp.cpu()[:, 0], g[f"J_pose_{sfx}"]) < 1e-5
-        assert relmax(jc.cpu()[:, 0], g[f"J_code_{sfx}"]) < 1e-5
+        assert relmax(jp.cpu()[:, 0], g[f"J_pose_{sfx}"]) < T(1e-5, 2e-3)
+        assert relmax(jc.cpu()[:, 0], g[f"J_code_{sfx}"]) < T(1e-5, 2e-3)
 
 
 @pytest.mark.parametrize("case", ["wild", "lab", "berry", "wild256"])
@@ -136,10 +137,10 @@ def test_render_loss_vs_golden(case):
         assert res_d.shape[0] == g[f"res_d_{f}"].shape[0]
         assert relmax(res_d.reshape(-1), g[f"res_d_{f}"]) < 2e-5
         assert relmax(res_m.reshape(-1), g[f"res_m_{f}"]) < 2e-5
-        assert relmax(jdp[:, 0], g[f"J_d_pose_{f}"]) < 2e-5
-        assert relmax(jdc[:, 0], g[f"J_d_code_{f}"]) < 2e-5
-        assert relmax(jmp[:, 0], g[f"J_m_pose_{f}"]) < 2e-5
-        assert relmax(jmc[:, 0], g[f"J_m_code_{f}"]) < 2e-5
+        assert relmax(jdp[:, 0], g[f"J_d_pose_{f}"]) < T(2e-5, 2e-3)
+        assert relmax(jdc[:, 0], g[f"J_d_code_{f}"]) < T(2e-5, 2e-3)
+        assert relmax(jmp[:, 0], g[f"J_m_pose_{f}"]) < T(2e-5, 2e-3)
+        assert relmax(jmc[:, 0], g[f"J_m_code_{f}"]) < T(2e-5, 2e-3)
 
 
 def test_render_loss_none_case():
@@ -176,26 +177,29 @@ def test_one_iteration_vs_golden(name):
     A = A + A.T - np.diag(np.diag(A))
     perm = list(range(L, L + P)) + list(range(L))          # reference unknown order [pose | code]
     Ar, br, dr = A[np.ix_(perm, perm)], dbg["b"][0].cpu().numpy()[perm], dbg["delta"][0].cpu().numpy()[perm]
-    assert relmax(Ar, g["H_free"]) < 1e-5
-    assert relmax(br, g["b_free"]) < 1e-5
-    assert relmax(dr, g["delta_free"]) < 2e-4
-    assert relmax(res.latent, g["z_free"]) < 2e-4 and relmax(res.T_ow, g["T_free"]) < 1e-5
+    assert relmax(Ar, g["H_free"]) < T(1e-5, 3e-3)
+    assert relmax(br, g["b_free"]) < T(1e-5, 3e-3)
+    assert relmax(dr, g["delta_free"]) < T(2e-4, 2e-2)
+    assert relmax(res.latent, g["z_free"]) < T(2e-4, 2e-2) and relmax(res.T_ow, g["T_free"]) < T(1e-5, 1e-3)
     tr = []
     O.shape_pose_joint_opt(od.to(torch.float64), cfg, torch.from_numpy(g["z0"]), torch.from_numpy(g["T_ow0"]),
                            render_data_from_golden(g), torch.from_numpy(g["points_w"]), float(g["cube_radius"]), trace=tr)
-    assert relmax(dr, tr[0].delta) < 5e-5                  # refined solve: closer to fp64 than the fp32 inverse bound
+    assert relmax(dr, tr[0].delta) < T(5e-5, 2e-2)         # refined solve: closer to fp64 than the fp32 inverse bound
     dbg = {}
     res = HO.optimize_batch(dec, cfg, [_instance(g, g["z0"])], shape_only=True, debug=dbg)[0]
     A = np.tril(dbg["A"][0].cpu().numpy()[:L, :L])
     A = A + A.T - np.diag(np.diag(A))
-    assert relmax(A, g["H_sdf"]) < 1e-5
-    assert relmax(dbg["b"][0].cpu().numpy()[:L], g["b_sdf"]) < 1e-5
-    assert relmax(dbg["delta"][0].cpu().numpy()[:L], g["delta_sdf"]) < 2e-4
-    assert relmax(res.latent, g["z_sdf"]) < 2e-4
+    assert relmax(A, g["H_sdf"]) < T(1e-5, 3e-3)
+    assert relmax(dbg["b"][0].cpu().numpy()[:L], g["b_sdf"]) < T(1e-5, 3e-3)
+    assert relmax(dbg["delta"][0].cpu().numpy()[:L], g["delta_sdf"]) < T(2e-4, 2e-2)
+    assert relmax(res.latent, g["z_sdf"]) < T(2e-4, 2e-2)
 
 
-_TOL = {"free_sim3_it5": (0.2, 5e-3), "exit_grad_free": (0.5, 2e-2), "free_sim3_it2": (2e-3, 2e-4),
-        "free_se3_it2": (2e-3, 2e-4), "invalid_later": (2e-3, 2e-4)}
+# State tolerances of the trajectory tests: the fp32 rounding class of a well-conditioned run (1e-3 latent, 1e-4 pose)
+# or THREE TIMES the deviation the reference loop itself shows when its surface points are scaled by 1 +- 1e-7
+# (fixture g16_traj_noise, made from the imported reference), whichever is larger.  No hand-picked constants: the
+# free-pose cases get their slack from the reference's own measured sensitivity.
+K_NOISE = 3.0
 _STATUS = {"exit_grad": 1, "exit_grad_free": 1, "sdf_exit_grad": 1, "exit_code": 2, "sdf_exit_code": 2,
            "invalid_at0": 16 | 64, "invalid_later": 16 | 64}     # 64: the frame was skipped ('This frame is not valid')
 
@@ -210,9 +214,10 @@ def test_trajectories_vs_golden(name):
     tag = name[len("g9_traj_"):]
     res = HO.optimize_batch(dec, cfg, [_instance(g, pose_known=bool(g["pose_known"]))],
                             shape_only=(str(g["kind"]) == "sdf"))[0]
-    assert res.iter_count == int(g["iter_count"])
+    nz, nT, nit = traj_noise(tag)
+    assert abs(res.iter_count - int(g["iter_count"])) <= T(K_NOISE * nit, max(K_NOISE * nit, 2))
     assert res.status == _STATUS.get(tag, 8), res.status
-    tz, tT = _TOL.get(tag, (1e-3, 1e-4))
+    tz, tT = max(T(1e-3, 3e-2), K_NOISE * nz), max(T(1e-4, 3e-3), K_NOISE * nT)
     if np.abs(g["z_out"]).max() > 0:
         assert relmax(res.latent, g["z_out"]) < tz
     else:
@@ -223,6 +228,7 @@ def test_trajectories_vs_golden(name):
 def test_optimizer_class_drop_in():
     """The reference call pattern: Optimizer(cfg, decoder, mesher, vis).shape_pose_joint_opt(...) (optimizer.py:17,28)."""
     from hortimapping_amd.optimizer import Optimizer
+    from tests.golden_util import T as T_
     g = load("g9_traj_known_sim3_it5")
     dec, _, _ = get_dec(g["decoder"])
     cfg = {"device": "cuda", "opt": cfg_from_golden(g), "vis": {"vis_pause_s": 0, "log_on": False, "vis_on": False}}
@@ -232,12 +238,12 @@ def test_optimizer_class_drop_in():
                                              torch.from_numpy(g["points_w"]), float(g["cube_radius"]), None,
                                              pose_known=True)
     assert out_lat is latent and n == 5                      # latent mutated in place AND returned (optimizer.py:248,302)
-    assert relmax(latent, g["z_out"]) < 1e-3 and relmax(T, g["T_out"]) < 1e-4
+    assert relmax(latent, g["z_out"]) < T_(1e-3, 3e-2) and relmax(T, g["T_out"]) < T_(1e-4, 3e-3)
     g = load("g9_traj_sdf_it5")
     latent = torch.from_numpy(g["latent0"].copy())
     T0 = torch.from_numpy(g["T_ow0"])
     out_lat, T, n = opt.shape_opt_deepsdf(latent, T0, torch.from_numpy(g["points_w"]), None)
-    assert n == 5 and T is T0 and relmax(latent, g["z_out"]) < 1e-3
+    assert n == 5 and T is T0 and relmax(latent, g["z_out"]) < T_(1e-3, 3e-2)
 
 
 def test_batched_equals_single_and_order_preserved():
@@ -323,8 +329,8 @@ def test_dense_random_decoder_vs_fp64_oracle(L):
         yo, go = O.decoder_jacobian(od, lat[b], pts[b])
         assert torch.isfinite(y[b]).all() and torch.isfinite(J[b]).all()
         assert float((y[b] - yo).abs().max() / yo.abs().max()) < 2e-5
-        assert float((J[b, :, :L] - go[:, :L]).abs().max() / go[:, :L].abs().max()) < 5e-5
-        assert float((J[b, :, L:L + 3] - go[:, L:]).abs().max() / go[:, L:].abs().max()) < 5e-5
+        assert float((J[b, :, :L] - go[:, :L]).abs().max() / go[:, :L].abs().max()) < T(5e-5, 5e-3)
+        assert float((J[b, :, L:L + 3] - go[:, L:]).abs().max() / go[:, L:].abs().max()) < T(5e-5, 5e-3)
 
 
 def test_f16x3_activation_overflow_is_reported():
@@ -342,10 +348,11 @@ def test_f16x3_activation_overflow_is_reported():
     inst = W.to_instance(d, pose_known=True)
     opt = W.c2_opt_cfg(max_iter=3)
     out = {}
-    for prec in ("f32", "f16x3"):
+    for prec in ("f32", "f16x3", "f16x3f_f16b"):
         dec = DecoderWeights.from_params(big)
         dec.set_precision(prec)
         out[prec] = HO.optimize_batch(dec, opt, [inst])[0]
     assert out["f32"].status == 8 and out["f32"].iter_count == 3 and torch.isfinite(out["f32"].latent).all()
-    assert out["f16x3"].status & 32 and out["f16x3"].iter_count < 3
-    assert torch.equal(out["f16x3"].latent, inst.latent)         # state left untouched by the failed step
+    for prec in ("f16x3", "f16x3f_f16b"):
+        assert out[prec].status & 32 and out[prec].iter_count < 3
+        assert torch.equal(out[prec].latent, inst.latent)        # state left untouched by the failed step

@@ -130,11 +130,10 @@ def _run_traj(g):
     return O.shape_opt_deepsdf(d, cfg, z0, T0, pw)
 
 
-# state-level trajectory parity holds in the well-conditioned modes (shape-only, pose_known) and for the first
-# iterations of free-pose runs; long free-pose trajectories diverge at the 1e-2 level between ANY two fp32
-# evaluations of the reference itself (SURVEY.md 8d "parity noise floor"), so they get a loose bound.
-_TOL = {"free_sim3_it5": (0.2, 5e-3), "exit_grad_free": (0.5, 2e-2), "free_sim3_it2": (2e-3, 1e-4),
-        "free_se3_it2": (2e-3, 1e-4), "invalid_later": (2e-3, 1e-4)}
+# State-level trajectory parity: fp32 rounding class (1e-3 latent, 1e-4 pose) in the well-conditioned modes; free-pose
+# trajectories amplify rounding noise, so their bound is K_NOISE x the deviation the REFERENCE ITSELF shows when its
+# surface points are scaled by 1 +- 1e-7 (fixture g16_traj_noise, tests/golden/make_golden_r2.py) -- measured, not chosen.
+K_NOISE = 3.0
 
 
 @pytest.mark.parametrize("name", list_golden("g9_traj_"))
@@ -143,7 +142,9 @@ def test_g9_trajectories(name):
     z, T, n = _run_traj(g)
     tag = name[len("g9_traj_"):]
     assert n == int(g["iter_count"]), (n, int(g["iter_count"]))
-    tz, tT = _TOL.get(tag, (1e-3, 1e-4))
+    from golden_util import traj_noise
+    nz, nT, _ = traj_noise(tag)
+    tz, tT = max(1e-3, K_NOISE * nz), max(1e-4, K_NOISE * nT)
     if np.abs(g["z_out"]).max() > 0:
-        assert relmax(z, g["z_out"]) < tz
-    assert relmax(T, g["T_out"]) < tT
+        assert relmax(z, g["z_out"]) < tz, (relmax(z, g["z_out"]), nz)
+    assert relmax(T, g["T_out"]) < tT, (relmax(T, g["T_out"]), nT)
