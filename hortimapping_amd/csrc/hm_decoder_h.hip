@@ -399,6 +399,16 @@ __global__ __launch_bounds__(512, 2) void k_decoder_h(const DecodeArgsH a) {
     if (MODE == 0 || epi <= EPI_FWD7) {
       const float* bias = bl + s * HID;
       uint2 mk = {0, 0};
+      // lin3's rows m..m+2 (always rows 29..31 of their block: m = 509 - L, L % 32 == 0) carry xyz into the skip layer:
+      // one (slot, g = 3, hi = 1) group of one wave, handled where it occurs instead of a test in every group
+      const int mbx = m >> 5;
+      // all bias vectors of this wave's rows first (one wait), then pure arithmetic + stores
+      f32x4 bv[2][4];
+#pragma unroll
+      for (int sl = 0; sl < 2; ++sl)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          bv[sl][g] = *reinterpret_cast<const f32x4*>(bias + (sl == 0 ? mb0 : mb1) * 32 + 8 * g + 4 * hi);
 #pragma unroll
       for (int sl = 0; sl < 2; ++sl) {
         const bool use = sl == 0 ? u0 : u1;
@@ -408,25 +418,20 @@ __global__ __launch_bounds__(512, 2) void k_decoder_h(const DecodeArgsH a) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const int f4 = mb * 32 + 8 * g + 4 * hi;
-          const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + f4);
 #pragma unroll
           for (int nb = 0; nb < 2; ++nb) {
             float v[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-              const float val = fmaf(acc[sl][nb][4 * g + j], us, bv[j]);
+              const float val = fmaf(acc[sl][nb][4 * g + j], us, bv[sl][g][j]);
               const bool pos = val > 0.f;
               bits |= (pos ? 1u : 0u) << (nb * 16 + 4 * g + j);
               v[j] = pos ? val : 0.f;
             }
             xmax = fmaxf(xmax, fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])));
-            if (epi == EPI_FWD3) {
+            if (g == 3 && epi == EPI_FWD3 && mb == mbx && hi == 1) {
               const f32x4 p = pts4[qbase + nb * 32 + qa];
-#pragma unroll
-              for (int j = 0; j < 4; ++j) {
-                const int r = f4 + j - m;
-                if (r >= 0 && r < 3) v[j] = (r == 0 ? p[0] : (r == 1 ? p[1] : p[2]));
-              }
+              v[1] = p[0]; v[2] = p[1]; v[3] = p[2];
             }
             split_store(xh4, xl4, ((f4 >> 3) * TQ + nb * 32 + qa) * 2 + hi, v);
           }

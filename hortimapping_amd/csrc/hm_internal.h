@@ -43,6 +43,7 @@ struct SolveArgs {
   int L, P, ldJ, ld_latent;
   int iter, max_iter;
   int lm_on, lm_eye, scale_on;
+  int force_direct;        // 1: skip the PCG fast path of the solve (tests of the Cholesky fallback)
   float w_code, s_damp, lam0;
   float eps_g, eps_c, eps_t, eps_r, eps_s;
 };

@@ -8,6 +8,7 @@
 //   normal eqs   (:152-159,189-190,200-231) K4 (all terms in one pass) -> K5 (assemble, solve, update, converge)
 // There is no host<->device synchronisation inside the loop: per-instance `active` flags freeze finished
 // instances, and every data-dependent size (ball-valid samples, Jacobian samples, emitted rays) stays on the device.
+#include <stdlib.h>
 #include <string.h>
 
 #include <vector>
@@ -263,6 +264,9 @@ extern "C" int hm_optimize_batch(hm_workspace_s* ws, const hm_opt_cfg* cfg, cons
   RenderCfg rcfg = make_render_cfg(ws, cfg);
   RenderBuffers rb = ws->rb;
   if (mode == 0) { bind_inputs(rb, bt); rb.status = bt->d_status; }
+  // test hook: HM_FORCE_DIRECT_SOLVE=1 sends every system through the Cholesky fallback of the solve kernel
+  const char* fd = getenv("HM_FORCE_DIRECT_SOLVE");
+  const int force_direct = (fd != nullptr && fd[0] == '1') ? 1 : 0;
 
   for (int it = 0; it < cfg->max_iter; ++it) {
     rc = launch_latent_bias(ws->dec, bt->d_latent, L, ws->active, B, ws->c0, ws->c4, st);
@@ -315,6 +319,7 @@ extern "C" int hm_optimize_batch(hm_workspace_s* ws, const hm_opt_cfg* cfg, cons
     sa.w_code = cfg->w_codereg; sa.s_damp = cfg->s_damp; sa.lam0 = cfg->lm_lambda_0;
     sa.eps_g = cfg->epsilon_g; sa.eps_c = cfg->epsilon_c; sa.eps_t = cfg->epsilon_t; sa.eps_r = cfg->epsilon_r;
     sa.eps_s = cfg->epsilon_s;
+    sa.force_direct = force_direct;
     if (dbg && dbg->d_counts && mode == 0)
       hipLaunchKernelGGL(k_collect_counts, dim3((B + 63) / 64), dim3(64), 0, st, rcfg, rb, B, dbg->d_counts);
     rc = launch_solve_update(sa, B, st);

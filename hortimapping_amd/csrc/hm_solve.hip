@@ -149,17 +149,279 @@ __device__ void solve_packed(const float* Lp, float* rv, int E, int tid, bool fo
 
 __device__ long long* g_k5_trace = nullptr;
 
+// ---------------------------------------------------------------------------------------------------------------
+// Fast path of the solve: Jacobi-preconditioned conjugate gradients on the damped normal matrix.
+//
+// The system the reference inverts (optimizer.py:200-234) is  A = H + w_code I_z + s_damp e_s e_s^T + lambda_0 diag(.)
+// (or + lambda_0 max(diag) I): symmetric positive definite and, with the shipped lambda_0 = 0.1, WELL conditioned once
+// scaled by its diagonal -- measured cond(D^-1/2 A D^-1/2) = 70 ... 210 on the c2_joint systems, so PCG reaches a 1e-7
+// relative residual in 22 ... 26 iterations (solution within 1e-6 of the fp64 solve; the reference's own fp32
+// inverse + mv is 3e-7 ... 6e-7 off it).  One iteration is a 263 x 263 symmetric mat-vec out of LDS: about 3k cycles,
+// against 515k cycles for the blocked Cholesky + two triangular solves + fp64 refinement, whose 288-step pivot chain
+// (a wave-wide LDS round trip per pivot) cannot be shortened.  The direct solver stays as the fallback for systems
+// on which CG does not reach the tolerance within CG_MAXIT iterations (lm_on = false, tiny lambda_0, degenerate
+// observations ...): slow convergence IS the conditioning test -- there a small residual would not bound the error,
+// and the refined direct solve is the accurate one.  The choice is made per instance on the device; both paths are
+// deterministic.
+// Storage: strictly lower triangle, row-major, rows padded to whole float4s (rows 4g .. 4g+3 hold 4 (g + 1) floats),
+// diagonal slot and padding zero; the diagonal lives in diagA.  Every element is read ONCE per mat-vec with 16-byte
+// loads and used for both the row dot product (reduced inside a 16-lane DPP row) and the column sums (per-lane
+// accumulators, merged in a fixed order).
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int CG_ROWS = (MAX_E + 3) / 4 * 4;                     // 264
+constexpr int CG_G = CG_ROWS / 4;                                 // 66 row groups
+constexpr int CG_FLOATS = 4 * CG_G * (2 * (CG_G - 1) + 4) + 4;    // 4 (g+1)(2g + r) at g = CG_G - 1, r = 4 (35376) + one zero float4
+constexpr int CG_MAXIT = 48;           // the damped systems need 25 ... 31; beyond 48 the direct path runs
+constexpr float CG_TOL = 1e-7f;        // relative residual (preconditioned norm) at which the iteration stops
+
+__device__ __forceinline__ int cg_off4(int i) { const int g = i >> 2; return (g + 1) * (2 * g + (i & 3)); }   // float4 units
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float wave_sum_f(float v) {
+  v += dpp_f<0xB1>(v);     // quad_perm [1,0,3,2]
+  v += dpp_f<0x4E>(v);     // quad_perm [2,3,0,1]
+  v += dpp_f<0x141>(v);    // row_half_mirror
+  v += dpp_f<0x140>(v);    // row_mirror: every lane of a 16-lane row holds the row total
+  return (rdlane(v, 0) + rdlane(v, 16)) + (rdlane(v, 32) + rdlane(v, 48));
+}
+
+// Workgroup sum of one value per thread, fixed order (deterministic).  `red` : NT / 64 floats of LDS.
+__device__ __forceinline__ float block_sum(float v, float* red, int lane, int wv) {
+  v = wave_sum_f(v);
+  if (lane == 0) red[wv] = v;
+  __syncthreads();
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NT / 64; ++i) s += red[i];
+  __syncthreads();
+  return s;
+}
+
+__device__ __forceinline__ void block_sum2(float v0, float v1, float& s0, float& s1, float* red, int lane, int wv) {
+  v0 = wave_sum_f(v0);
+  v1 = wave_sum_f(v1);
+  if (lane == 0) { red[wv] = v0; red[NT / 64 + wv] = v1; }
+  __syncthreads();
+  s0 = 0.f; s1 = 0.f;
+#pragma unroll
+  for (int i = 0; i < NT / 64; ++i) { s0 += red[i]; s1 += red[NT / 64 + i]; }
+  __syncthreads();
+}
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// v[lane] + v[lane ^ 16] + v[lane ^ 32] + v[lane ^ 48] in every lane: two gfx950 lane-swap instructions (VALU speed; the
+// ds_bpermute route costs an LDS round trip per step).  v_permlane16_swap a, b leaves a = [a0 b0 a2 b2], b = [a1 b1 a3 b3]
+// (16-lane rows), v_permlane32_swap a = [a_lo b_lo], b = [a_hi b_hi]; with both registers holding v, a + b is the
+// pairwise sum.  Inline asm on purpose: hipcc (ROCm 7.2) folds __builtin_amdgcn_permlane16_swap(u, u) into "both results
+// equal" and emits a + a (measured on gfx950: every row got 4 x row 0); the s_nop covers the VALU-write -> permlane hazard.
+__device__ __forceinline__ float sum_dpp_rows(float v) {
+  float a = v, b = v;
+  asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));       // not volatile: a pure function of (a, b),
+  float s = a + b, t = s;                                                     // free to be scheduled among its siblings
+  asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(s), "+v"(t));
+  return s + t;
+}
+__device__ __forceinline__ float wave_sum_fast(float v) {       // whole-wave sum in every lane
+  v += dpp_f<0xB1>(v);
+  v += dpp_f<0x4E>(v);
+  v += dpp_f<0x141>(v);
+  v += dpp_f<0x140>(v);
+  return sum_dpp_rows(v);
+}
+
+// Returns true when x (LDS, E entries) solves A x = b: CG stopped at a CG_TOL relative residual in the PRECONDITIONED
+// norm sqrt(r . M^-1 r) (the 2-norm of the Jacobi-scaled system, in which cond <= (1 + lambda_0) / lambda_0 * lambda_max
+// is bounded by the damping: 70 ... 210 measured, error <= cond * tol).  The plain 2-norm of r is dominated by the
+// large-gradient unknowns and lets the small-scale ones (pose entries) stop 1e-4 short -- golden case invalid_later.
+// `red`: 4 * (NT / 64) floats (two generations of two sums, so one barrier per reduction suffices).
+__device__ bool pcg_solve(const float* __restrict__ H, int ld, const float* diagA, const float* bvec, float* x, int E,
+                          float* Ap, float* pv, float* rv, float* qv, float* part, float* red, int tid) {
+  const int lane = tid & 63, wv = tid >> 6;
+  const int G = (E + 3) >> 2;
+  f32x4* Ap4 = reinterpret_cast<f32x4*>(Ap);
+  const bool trc = g_k5_trace != nullptr && blockIdx.x == 0 && tid == 0;
+  if (trc) g_k5_trace[17] = clock64();
+  // ---- strictly lower triangle of H -> LDS (diagonal slot and padding zero).  Flat over the padded float4 slots so that
+  // every thread has ~18 INDEPENDENT 16-byte global loads in flight (a row-by-row loop waits out one L2 round trip per
+  // row chunk: 250k cycles for this copy alone).  Slot f belongs to row group g with 2 g (g + 1) <= f < 2 (g + 1)(g + 2).
+  const int nslot = 2 * G * (G + 1);            // slot `nslot` (inside CG_FLOATS) is kept zero: target of masked reads
+  {
+    constexpr int NLD = (2 * CG_G * (CG_G + 1) + NT - 1) / NT;          // 18
+    f32x4 buf[NLD];
+#pragma unroll
+    for (int t = 0; t < NLD; ++t) {
+      const int f = tid + t * NT;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (f < nslot) {
+        int g = (int)((sqrtf(1.f + 2.f * (float)f) - 1.f) * 0.5f);
+        g += (2 * (g + 1) * (g + 2) <= f) ? 1 : 0;
+        g -= (2 * g * (g + 1) > f) ? 1 : 0;
+        const int rem = f - 2 * g * (g + 1);
+        int r = (int)((float)rem / (float)(g + 1));                      // rem < 4 (g + 1) <= 264: exact after the fix-up
+        r -= (r * (g + 1) > rem) ? 1 : 0;
+        r += ((r + 1) * (g + 1) <= rem) ? 1 : 0;
+        const int f4 = rem - r * (g + 1);
+        const int i = 4 * g + r, k0 = 4 * f4;
+        if (i < E && k0 < i) {
+          v = *reinterpret_cast<const f32x4*>(H + (size_t)i * ld + k0);     // ld % 4 == 0: 16-byte aligned
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = (k0 + e < i) ? v[e] : 0.f;
+        }
+      }
+      buf[t] = v;
+    }
+#pragma unroll
+    for (int t = 0; t < NLD; ++t) {
+      const int f = tid + t * NT;
+      if (f <= nslot) Ap4[f] = buf[t];          // f == nslot: the zero slot (buf is zero there)
+    }
+  }
+  float ri = 0.f, di = 1.f;
+  if (tid < CG_ROWS) {
+    ri = tid < E ? bvec[tid] : 0.f;
+    di = tid < E ? diagA[tid] : 1.f;
+    x[tid] = 0.f;
+    rv[tid] = ri;
+    pv[tid] = ri / di;
+  }
+  if (trc) g_k5_trace[18] = clock64();
+  int gen = 0;
+  auto sums2 = [&](float v0, float v1, float& s0, float& s1) {   // two workgroup sums, ONE barrier (red is two-generation)
+    v0 = wave_sum_fast(v0);
+    v1 = wave_sum_fast(v1);
+    float* rg = red + gen * 2 * (NT / 64);
+    gen ^= 1;
+    if (lane == 0) { rg[wv] = v0; rg[NT / 64 + wv] = v1; }
+    __syncthreads();
+    s0 = 0.f; s1 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NT / 64; ++i) { s0 += rg[i]; s1 += rg[NT / 64 + i]; }
+  };
+  auto sum1 = [&](float v0) {                   // one workgroup sum, one barrier
+    v0 = wave_sum_fast(v0);
+    float* rg = red + gen * 2 * (NT / 64);
+    gen ^= 1;
+    if (lane == 0) rg[wv] = v0;
+    __syncthreads();
+    float s0 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NT / 64; ++i) s0 += rg[i];
+    return s0;
+  };
+  float rz, bb;
+  sums2(ri * (ri / di), ri * ri, rz, bb);       // (the barrier also publishes pv / rv / x and the matrix)
+  if (!(bb > 0.f)) return bb == 0.f;            // b = 0: x = 0 is the solution; NaN: let the direct path report it
+  const float rz_stop = CG_TOL * CG_TOL * rz;
+  // mat-vec geometry: a wave takes FOUR matrix rows at a time, one per 16-lane DPP row; lane (r, j) covers the columns
+  // 4 (j + 16 c) .. + 3, c = 0..3, of row 4 g + r (conflict-free 16-byte reads: consecutive lanes, consecutive float4s).
+  // The row dot products then reduce INSIDE a DPP row (four v_add_dpp, no cross-row traffic, all four rows at once);
+  // the column sums stay in 16 registers per lane and are merged across DPP rows (lane swaps) / waves (LDS, fixed order)
+  // once per mat-vec.  Packed fp32 FMAs (v_pk_fma_f32) halve the instruction count of the products.
+  const int dr = lane >> 4, dj = lane & 15;
+  bool conv = false;
+  for (int it = 0; it < CG_MAXIT; ++it) {
+    const bool tri = trc && it == 1;
+    if (tri) g_k5_trace[19] = clock64();
+    if (trc) g_k5_trace[25] = it + 1;
+    // ---- q = A p ----
+    // c = 0..3: float4 columns dj + 16 c (columns < 256); c = 4: float4 64 + dj for dj < 2 (columns 256 .. 263, which
+    // exist only in the row groups g >= 64).  The group loop has a static trip count (CG_G / 8 rounded up) and no
+    // branches -- lanes outside a row, and whole rounds past the last group, read the zero slot -- so that hipcc
+    // unrolls it and keeps the LDS reads of the following groups in flight under the products of the current one.
+    f32x2 plo[5], phi[5], calo[5], cahi[5];
+#pragma unroll
+    for (int c = 0; c < 5; ++c) {
+      const f32x4 t4 = (c < 4 || dj < 2) ? reinterpret_cast<const f32x4*>(pv)[dj + 16 * c] : f32x4{0.f, 0.f, 0.f, 0.f};
+      plo[c] = f32x2{t4[0], t4[1]}; phi[c] = f32x2{t4[2], t4[3]};
+      calo[c] = f32x2{0.f, 0.f}; cahi[c] = f32x2{0.f, 0.f};
+    }
+    constexpr int NROUND = (CG_G + NT / 64 - 1) / (NT / 64);         // 9
+#pragma unroll
+    for (int t = 0; t < NROUND; ++t) {
+      const int g = wv + t * (NT / 64);
+      const bool live = g < G;
+      const int gc = live ? g : 0;
+      const int i = 4 * gc + dr;
+      const int o4 = cg_off4(i);
+      const float pi_ = pv[i];
+      const f32x2 pi2 = {pi_, pi_};
+      f32x2 rs2 = {0.f, 0.f};
+#pragma unroll
+      for (int c = 0; c < 5; ++c) {
+        if (c == 4 && t < 64 / (NT / 64)) continue;                  // columns >= 256 exist from group 64 on (t = 8)
+        const int f4 = dj + 16 * c;
+        const bool in = live && f4 <= gc && (c < 4 || dj < 2);
+        const f32x4 av = Ap4[in ? o4 + f4 : nslot];                  // outside the padded row: the zero slot
+        const f32x2 alo = {av[0], av[1]}, ahi = {av[2], av[3]};
+        rs2 = alo * plo[c] + rs2;
+        rs2 = ahi * phi[c] + rs2;
+        calo[c] = alo * pi2 + calo[c];
+        cahi[c] = ahi * pi2 + cahi[c];
+      }
+      float rsum = rs2[0] + rs2[1];
+      rsum += dpp_f<0xB1>(rsum);
+      rsum += dpp_f<0x4E>(rsum);
+      rsum += dpp_f<0x141>(rsum);
+      rsum += dpp_f<0x140>(rsum);
+      if (live && dj == 0) qv[i] = rsum;
+    }
+    if (tri) g_k5_trace[20] = clock64();
+    // column sums: across the four DPP rows of the wave (lane swaps), then across waves through LDS (fixed order)
+#pragma unroll
+    for (int c = 0; c < 5; ++c) {
+      const f32x4 t4 = {sum_dpp_rows(calo[c][0]), sum_dpp_rows(calo[c][1]), sum_dpp_rows(cahi[c][0]), sum_dpp_rows(cahi[c][1])};
+      if (dr == 0 && (c < 4 || dj < 2)) reinterpret_cast<f32x4*>(part + wv * CG_ROWS)[dj + 16 * c] = t4;
+    }
+    __syncthreads();
+    if (tri) g_k5_trace[21] = clock64();
+    float qi = 0.f, pi = 0.f;
+    if (tid < E) {
+      pi = pv[tid];
+      float cs = 0.f;
+#pragma unroll
+      for (int w2 = 0; w2 < NT / 64; ++w2) cs += part[w2 * CG_ROWS + tid];
+      qi = fmaf(di, pi, qv[tid] + cs);
+    }
+    const float pq = sum1(pi * qi);
+    if (tri) g_k5_trace[22] = clock64();
+    if (!(pq > 0.f)) break;                     // not positive definite / not finite: direct path decides
+    const float alpha = rz / pq;
+    float zi = 0.f;
+    if (tid < E) {
+      x[tid] = fmaf(alpha, pi, x[tid]);
+      ri = fmaf(-alpha, qi, ri);                // the residual entry of this thread lives in a register
+      zi = ri / di;
+    }
+    const float rz1 = sum1(ri * zi);
+    if (rz1 <= rz_stop) { conv = true; break; }
+    const float beta = rz1 / rz;
+    rz = rz1;
+    if (tid < E) pv[tid] = fmaf(beta, pi, zi);
+    __syncthreads();
+    if (tri) g_k5_trace[27] = clock64();
+  }
+  __syncthreads();
+  return conv;                                  // false: slow convergence or breakdown -> direct solver
+}
+
 __global__ __launch_bounds__(NT) void k_solve_update(const SolveArgs a) {
   // one LDS array, two lives: the 32-column panel [NBK][32][PS] during the factorisation, then the packed factor
-  __shared__ float smem[MAX_E * (MAX_E + 1) / 2];
+  __shared__ __attribute__((aligned(16))) float smem[CG_FLOATS];   // >= MAX_E (MAX_E + 1) / 2 of the direct path
+  __shared__ __attribute__((aligned(16))) float cg_p[CG_ROWS];
+  __shared__ __attribute__((aligned(16))) float cg_q[CG_ROWS];
+  __shared__ __attribute__((aligned(16))) float cg_part[(NT / 64) * CG_ROWS];
   __shared__ float bvec[NBK * 32];
-  __shared__ float xvec[NBK * 32];
+  __shared__ __attribute__((aligned(16))) float xvec[NBK * 32];
   __shared__ __attribute__((aligned(16))) float rv[NBK * 32];
   __shared__ float diagA[NBK * 32];
   __shared__ double cs[NBK * 32], rs[NBK * 32];   // fp64 column / row sums of the refinement residual
   __shared__ __attribute__((aligned(16))) float colk[32];
   __shared__ float dinv[32];
-  __shared__ float red[NT / 64];
+  __shared__ float red[4 * (NT / 64)];
   __shared__ float red2[NT / 64];
   __shared__ int flag;
 
@@ -228,250 +490,257 @@ __global__ __launch_bounds__(NT) void k_solve_update(const SolveArgs a) {
     for (int i = tid; i < E; i += NT) a.dbg_b[(size_t)b * ld + i] = bvec[i];
   if (trc) g_k5_trace[1] = clock64();
 
-  // ---- blocked right-looking Cholesky, 32-column panels, trailing update on the fp32 matrix cores ----
-  // When the last 32-row block has a spare row (E not a multiple of 32, i.e. joint mode) the right-hand side rides
-  // along as row E of the bordered matrix [[A, b], [b^T, c]]: its Cholesky factor's row E IS y = L^-1 b, so the
-  // forward sweep of the first triangular solve costs one more panel row instead of nine barrier-separated block
-  // steps.  c only has to keep the last pivot positive (1e30).
-  const bool aug = (E & 31) != 0;
-  // Wave w owns the lower-triangular 32x32 blocks p = w, w+8, ... (p = bi(bi+1)/2 + bk) in MFMA C layout.
-  const int cc = lane & 31, hh = lane >> 5;
-  f32x16 blk[NSLOT];
-  int obi[NSLOT], obk[NSLOT];
-#pragma unroll
-  for (int sl = 0; sl < NSLOT; ++sl) {
-    const int p = wv + (NT / 64) * sl;
-    int bi = 0;
-    while ((bi + 1) * (bi + 2) / 2 <= p) ++bi;
-    const int bk = p - bi * (bi + 1) / 2;
-    obi[sl] = bi < nblk ? bi : -1;
-    obk[sl] = bk;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int i = bi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh, k = bk * 32 + cc;
-      float v = (i == k) ? 1.f : 0.f;                           // padding: identity
-      if (bi < nblk && i < E && k < E) v = (i == k) ? diagA[i] : (k < i ? H[(size_t)i * ld + k] : H[(size_t)k * ld + i]);
-      if (aug && bi < nblk && (i == E || k == E))               // bordered system [[A, b], [b^T, c]], see below
-        v = (i == E && k == E) ? 1e30f : (i == E ? (k < E ? bvec[k] : 0.f) : (i < E ? bvec[i] : 0.f));
-      blk[sl][r] = v;
-    }
-  }
-  float* Pn = smem;                                             // panel: Pn[(bi * 32 + row) * PS + col]
-  for (int bj = 0; bj < nblk; ++bj) {
-    const bool trj = trc && bj == 0;          // phase stamps of the first (largest) block column
-    if (trj) g_k5_trace[8] = clock64();
-    // 1. owners of block column bj publish their blocks
-#pragma unroll
-    for (int sl = 0; sl < NSLOT; ++sl)
-      if (obi[sl] >= 0 && obk[sl] == bj) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-          Pn[(obi[sl] * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh) * PS + cc] = blk[sl][r];
+  // ---- solve A x = b: preconditioned CG (fast path), blocked Cholesky + refinement (fallback) ----
+  static_assert(CG_FLOATS >= MAX_E * (MAX_E + 1) / 2 && CG_ROWS <= NBK * 32, "LDS plan");
+  const bool cg_ok = !a.force_direct && pcg_solve(H, ld, diagA, bvec, xvec, E, smem, cg_p, rv, cg_q, cg_part, red, tid);
+  if (trc) g_k5_trace[2] = clock64();
+  if (!cg_ok) {
+    // ---- blocked right-looking Cholesky, 32-column panels, trailing update on the fp32 matrix cores ----
+    // When the last 32-row block has a spare row (E not a multiple of 32, i.e. joint mode) the right-hand side rides
+    // along as row E of the bordered matrix [[A, b], [b^T, c]]: its Cholesky factor's row E IS y = L^-1 b, so the
+    // forward sweep of the first triangular solve costs one more panel row instead of nine barrier-separated block
+    // steps.  c only has to keep the last pivot positive (1e30).
+    const bool aug = (E & 31) != 0;
+    // Wave w owns the lower-triangular 32x32 blocks p = w, w+8, ... (p = bi(bi+1)/2 + bk) in MFMA C layout.
+    const int cc = lane & 31, hh = lane >> 5;
+    f32x16 blk[NSLOT];
+    int obi[NSLOT], obk[NSLOT];
+  #pragma unroll
+    for (int sl = 0; sl < NSLOT; ++sl) {
+      const int p = wv + (NT / 64) * sl;
+      int bi = 0;
+      while ((bi + 1) * (bi + 2) / 2 <= p) ++bi;
+      const int bk = p - bi * (bi + 1) / 2;
+      obi[sl] = bi < nblk ? bi : -1;
+      obk[sl] = bk;
+  #pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int i = bi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh, k = bk * 32 + cc;
+        float v = (i == k) ? 1.f : 0.f;                           // padding: identity
+        if (bi < nblk && i < E && k < E) v = (i == k) ? diagA[i] : (k < i ? H[(size_t)i * ld + k] : H[(size_t)k * ld + i]);
+        if (aug && bi < nblk && (i == E || k == E))               // bordered system [[A, b], [b^T, c]], see below
+          v = (i == E && k == E) ? 1e30f : (i == E ? (k < E ? bvec[k] : 0.f) : (i < E ? bvec[i] : 0.f));
+        blk[sl][r] = v;
       }
-    __syncthreads();
-    if (trj) g_k5_trace[9] = clock64();
-    // 2. diagonal block: in-wave Cholesky, lane = row, columns in registers, broadcasts by v_readlane
-    if (wv == 0) {
-      float ar[32];
-      const float* src = Pn + (bj * 32 + cc) * PS;
-#pragma unroll
-      for (int k = 0; k < 32; ++k) ar[k] = src[k];
-      bool bad = false;
-#pragma unroll
-      for (int k = 0; k < 32; ++k) {
-        colk[cc] = ar[k];
-        __builtin_amdgcn_wave_barrier();
-        const float piv = colk[k];
-        bad |= !(piv > 0.f);
-        float y = __builtin_amdgcn_rsqf(piv);
-        y = y * fmaf(-0.5f * piv * y, y, 1.5f);
-        const float t = -ar[k] * (y * y);
-#pragma unroll
-        for (int g = (k + 1) / 4; g < 8; ++g) {
-          const f32x4 v = reinterpret_cast<const f32x4*>(colk)[g];
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (4 * g + e > k) ar[4 * g + e] = fmaf(t, v[e], ar[4 * g + e]);
+    }
+    float* Pn = smem;                                             // panel: Pn[(bi * 32 + row) * PS + col]
+    for (int bj = 0; bj < nblk; ++bj) {
+      const bool trj = trc && bj == 0;          // phase stamps of the first (largest) block column
+      if (trj) g_k5_trace[8] = clock64();
+      // 1. owners of block column bj publish their blocks
+  #pragma unroll
+      for (int sl = 0; sl < NSLOT; ++sl)
+        if (obi[sl] >= 0 && obk[sl] == bj) {
+  #pragma unroll
+          for (int r = 0; r < 16; ++r)
+            Pn[(obi[sl] * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh) * PS + cc] = blk[sl][r];
         }
-        __builtin_amdgcn_wave_barrier();
-        ar[k] = (cc == k) ? piv * y : ar[k] * y;
-        if (lane == k) dinv[k] = y;
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      if (bad) flag = 1;
-      if (lane < 32) {
-        float* dst = Pn + (bj * 32 + cc) * PS;
-#pragma unroll
-        for (int k = 0; k < 32; ++k) dst[k] = (k <= cc) ? ar[k] : 0.f;
-      }
-    }
-    if (trj) g_k5_trace[10] = clock64();
-    __syncthreads();
-    if (trj) g_k5_trace[11] = clock64();
-    // 3. panel below the diagonal block: row-wise forward substitution  x L11^T = a
-    {
-      const int nrow = (nblk - 1 - bj) * 32;
-      const float* L11 = Pn + bj * 32 * PS;
-      for (int t = tid; t < nrow; t += NT) {
-        float* row = Pn + ((bj + 1) * 32 + t) * PS;
-        float x[32];
-#pragma unroll
-        for (int k = 0; k < 32; ++k) x[k] = row[k];
-#pragma unroll
+      __syncthreads();
+      if (trj) g_k5_trace[9] = clock64();
+      // 2. diagonal block: in-wave Cholesky, lane = row, columns in registers, broadcasts by v_readlane
+      if (wv == 0) {
+        float ar[32];
+        const float* src = Pn + (bj * 32 + cc) * PS;
+  #pragma unroll
+        for (int k = 0; k < 32; ++k) ar[k] = src[k];
+        bool bad = false;
+  #pragma unroll
         for (int k = 0; k < 32; ++k) {
-          float sacc = x[k];
-#pragma unroll
-          for (int m2 = 0; m2 < k; ++m2) sacc = fmaf(-x[m2], L11[k * PS + m2], sacc);
-          x[k] = sacc / L11[k * PS + k];
+          colk[cc] = ar[k];
+          __builtin_amdgcn_wave_barrier();
+          const float piv = colk[k];
+          bad |= !(piv > 0.f);
+          float y = __builtin_amdgcn_rsqf(piv);
+          y = y * fmaf(-0.5f * piv * y, y, 1.5f);
+          const float t = -ar[k] * (y * y);
+  #pragma unroll
+          for (int g = (k + 1) / 4; g < 8; ++g) {
+            const f32x4 v = reinterpret_cast<const f32x4*>(colk)[g];
+  #pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (4 * g + e > k) ar[4 * g + e] = fmaf(t, v[e], ar[4 * g + e]);
+          }
+          __builtin_amdgcn_wave_barrier();
+          ar[k] = (cc == k) ? piv * y : ar[k] * y;
+          if (lane == k) dinv[k] = y;
           __builtin_amdgcn_sched_barrier(0);
         }
-#pragma unroll
-        for (int k = 0; k < 32; ++k) row[k] = x[k];
-      }
-    }
-    if (trj) g_k5_trace[12] = clock64();
-    __syncthreads();
-    if (trj) g_k5_trace[13] = clock64();
-    // 4. trailing update  A22 -= L21 L21^T  on the matrix cores, and the finished panel goes to global scratch
-#pragma unroll
-    for (int sl = 0; sl < NSLOT; ++sl)
-      if (obi[sl] >= 0 && obk[sl] > bj) {
-        const float* pa = Pn + (obi[sl] * 32 + cc) * PS + 4 * hh;
-        const float* pb = Pn + (obk[sl] * 32 + cc) * PS + 4 * hh;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const f32x4 av = *reinterpret_cast<const f32x4*>(pa + 8 * g);
-          const f32x4 bv = *reinterpret_cast<const f32x4*>(pb + 8 * g);
-#pragma unroll
-          for (int t = 0; t < 4; ++t)
-            blk[sl] = __builtin_amdgcn_mfma_f32_32x32x2f32(-av[t], bv[t], blk[sl], 0, 0, 0);
+        if (bad) flag = 1;
+        if (lane < 32) {
+          float* dst = Pn + (bj * 32 + cc) * PS;
+  #pragma unroll
+          for (int k = 0; k < 32; ++k) dst[k] = (k <= cc) ? ar[k] : 0.f;
         }
       }
-    {
-      const int nel = (nblk - bj) * 32 * 32;
-      for (int e = tid; e < nel; e += NT) {
-        const int r = e >> 5, k = e & 31;
-        Lg[(size_t)(bj * 32 + r) * LGS + bj * 32 + k] = Pn[(bj * 32 + r) * PS + k];
-      }
-    }
-    if (trj) g_k5_trace[14] = clock64();
-    __syncthreads();
-    if (trj) g_k5_trace[15] = clock64();
-  }
-  if (flag) {
-    if (tid == 0) { a.active[b] = 0; a.status[b] |= HM_STATUS_SOLVE_FAILED; }
-    return;
-  }
-  if (trc) g_k5_trace[2] = clock64();
-  // packed factor into LDS (the panel area is dead now), then invert its diagonal blocks in place
-  __threadfence_block();
-  float* Lp = smem;
-  for (int i = tid >> 5; i < E; i += NT / 32)
-    for (int k = tid & 31; k <= i; k += 32) Lp[tri(i, k)] = Lg[(size_t)i * LGS + k];
-  __syncthreads();
-  {
-    // column `cc` of inverse(L11): x[k] = Linv[k][cc], forward substitution on e_cc with broadcast reads of L11.
-    // Each half-wave takes one diagonal block (blocks w and w + 8 in wave w): all nine blocks in a single pass.
-    const int bb = wv + (NT / 64) * hh;
-    if (bb < nblk) {
-      const int base = bb * 32;
-      float x[32];
-      // row k of L11 (k + 1 broadcast reads) is fetched one row AHEAD of its use: the forward substitution then costs
-      // one LDS latency per row overlapped with the previous row's dot product, instead of a round trip per element
-      float cur[32], nxt[32];
+      if (trj) g_k5_trace[10] = clock64();
+      __syncthreads();
+      if (trj) g_k5_trace[11] = clock64();
+      // 3. panel below the diagonal block: row-wise forward substitution  x L11^T = a
       {
-        const float* lr = Lp + tri(base, base);
-        cur[0] = lr[0];
-      }
-#pragma unroll
-      for (int k = 0; k < 32; ++k) {
-        const int i = base + k;
-        if (k + 1 < 32) {
-          const int in = i + 1 < E ? i + 1 : base;               // rows past E are never used (x stays 0)
-          const float* lr = Lp + tri(in, base);
-#pragma unroll
-          for (int m2 = 0; m2 <= k + 1; ++m2) nxt[m2] = lr[m2];
+        const int nrow = (nblk - 1 - bj) * 32;
+        const float* L11 = Pn + bj * 32 * PS;
+        for (int t = tid; t < nrow; t += NT) {
+          float* row = Pn + ((bj + 1) * 32 + t) * PS;
+          float x[32];
+  #pragma unroll
+          for (int k = 0; k < 32; ++k) x[k] = row[k];
+  #pragma unroll
+          for (int k = 0; k < 32; ++k) {
+            float sacc = x[k];
+  #pragma unroll
+            for (int m2 = 0; m2 < k; ++m2) sacc = fmaf(-x[m2], L11[k * PS + m2], sacc);
+            x[k] = sacc / L11[k * PS + k];
+            __builtin_amdgcn_sched_barrier(0);
+          }
+  #pragma unroll
+          for (int k = 0; k < 32; ++k) row[k] = x[k];
         }
-        __builtin_amdgcn_sched_barrier(0);
-        float s0 = (k == cc) ? 1.f : 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-#pragma unroll
-        for (int m2 = 0; m2 < k; ++m2) {
-          if ((m2 & 3) == 0) s0 = fmaf(-x[m2], cur[m2], s0);
-          else if ((m2 & 3) == 1) s1 = fmaf(-x[m2], cur[m2], s1);
-          else if ((m2 & 3) == 2) s2 = fmaf(-x[m2], cur[m2], s2);
-          else s3 = fmaf(-x[m2], cur[m2], s3);
-        }
-        x[k] = (i < E && k >= cc) ? ((s0 + s1) + (s2 + s3)) / cur[k] : 0.f;
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int m2 = 0; m2 <= k + 1 && m2 < 32; ++m2) cur[m2] = nxt[m2];
       }
-      __builtin_amdgcn_wave_barrier();
-#pragma unroll
-      for (int k = 0; k < 32; ++k)
-        if (k >= cc && base + k < E && base + cc < E) Lp[tri(base + k, base + cc)] = x[k];
+      if (trj) g_k5_trace[12] = clock64();
+      __syncthreads();
+      if (trj) g_k5_trace[13] = clock64();
+      // 4. trailing update  A22 -= L21 L21^T  on the matrix cores, and the finished panel goes to global scratch
+  #pragma unroll
+      for (int sl = 0; sl < NSLOT; ++sl)
+        if (obi[sl] >= 0 && obk[sl] > bj) {
+          const float* pa = Pn + (obi[sl] * 32 + cc) * PS + 4 * hh;
+          const float* pb = Pn + (obk[sl] * 32 + cc) * PS + 4 * hh;
+  #pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const f32x4 av = *reinterpret_cast<const f32x4*>(pa + 8 * g);
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(pb + 8 * g);
+  #pragma unroll
+            for (int t = 0; t < 4; ++t)
+              blk[sl] = __builtin_amdgcn_mfma_f32_32x32x2f32(-av[t], bv[t], blk[sl], 0, 0, 0);
+          }
+        }
+      {
+        const int nel = (nblk - bj) * 32 * 32;
+        for (int e = tid; e < nel; e += NT) {
+          const int r = e >> 5, k = e & 31;
+          Lg[(size_t)(bj * 32 + r) * LGS + bj * 32 + k] = Pn[(bj * 32 + r) * PS + k];
+        }
+      }
+      if (trj) g_k5_trace[14] = clock64();
+      __syncthreads();
+      if (trj) g_k5_trace[15] = clock64();
     }
-  }
-  __syncthreads();
+    if (flag) {
+      if (tid == 0) { a.active[b] = 0; a.status[b] |= HM_STATUS_SOLVE_FAILED; }
+      return;
+    }
+    if (trc) g_k5_trace[16] = clock64();
+    // packed factor into LDS (the panel area is dead now), then invert its diagonal blocks in place
+    __threadfence_block();
+    float* Lp = smem;
+    for (int i = tid >> 5; i < E; i += NT / 32)
+      for (int k = tid & 31; k <= i; k += 32) Lp[tri(i, k)] = Lg[(size_t)i * LGS + k];
+    __syncthreads();
+    {
+      // column `cc` of inverse(L11): x[k] = Linv[k][cc], forward substitution on e_cc with broadcast reads of L11.
+      // Each half-wave takes one diagonal block (blocks w and w + 8 in wave w): all nine blocks in a single pass.
+      const int bb = wv + (NT / 64) * hh;
+      if (bb < nblk) {
+        const int base = bb * 32;
+        float x[32];
+        // row k of L11 (k + 1 broadcast reads) is fetched one row AHEAD of its use: the forward substitution then costs
+        // one LDS latency per row overlapped with the previous row's dot product, instead of a round trip per element
+        float cur[32], nxt[32];
+        {
+          const float* lr = Lp + tri(base, base);
+          cur[0] = lr[0];
+        }
+  #pragma unroll
+        for (int k = 0; k < 32; ++k) {
+          const int i = base + k;
+          if (k + 1 < 32) {
+            const int in = i + 1 < E ? i + 1 : base;               // rows past E are never used (x stays 0)
+            const float* lr = Lp + tri(in, base);
+  #pragma unroll
+            for (int m2 = 0; m2 <= k + 1; ++m2) nxt[m2] = lr[m2];
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          float s0 = (k == cc) ? 1.f : 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  #pragma unroll
+          for (int m2 = 0; m2 < k; ++m2) {
+            if ((m2 & 3) == 0) s0 = fmaf(-x[m2], cur[m2], s0);
+            else if ((m2 & 3) == 1) s1 = fmaf(-x[m2], cur[m2], s1);
+            else if ((m2 & 3) == 2) s2 = fmaf(-x[m2], cur[m2], s2);
+            else s3 = fmaf(-x[m2], cur[m2], s3);
+          }
+          x[k] = (i < E && k >= cc) ? ((s0 + s1) + (s2 + s3)) / cur[k] : 0.f;
+          __builtin_amdgcn_sched_barrier(0);
+  #pragma unroll
+          for (int m2 = 0; m2 <= k + 1 && m2 < 32; ++m2) cur[m2] = nxt[m2];
+        }
+        __builtin_amdgcn_wave_barrier();
+  #pragma unroll
+        for (int k = 0; k < 32; ++k)
+          if (k >= cc && base + k < E && base + cc < E) Lp[tri(base + k, base + cc)] = x[k];
+      }
+    }
+    __syncthreads();
 
-  // ---- solve L L^T x = b (fp32), then one refinement step with an fp64 residual from the fp32 system ----
-  for (int i = tid; i < NBK * 32; i += NT) {
-    rv[i] = i < E ? (aug ? Lg[(size_t)E * LGS + i] : bvec[i]) : 0.f;     // aug: y = row E of the bordered factor
-    xvec[i] = 0.f;
-  }
-  __syncthreads();
-  solve_packed(Lp, rv, E, tid, !aug);
-  if (trc) g_k5_trace[3] = clock64();
-  for (int i = tid; i < E; i += NT) xvec[i] = rv[i];
-  __syncthreads();
-  // r = b - A x in fp64 from the fp32 system.  Only the lower triangle of H is valid; one sweep over it with
-  // row-contiguous (coalesced) reads serves both halves of the symmetric product: element H[i][k] (k < i) adds
-  // H[i][k] x[k] to row i (wave reduction) and H[i][k] x[i] to column k (per-lane accumulators, merged with LDS fp64
-  // atomics at the end).  Eleven rows per wave (a third of its share) are in flight at a time to cover the load latency.
-  for (int k = tid; k < NBK * 32; k += NT) { cs[k] = k < E ? (double)diagA[k] * (double)xvec[k] : 0.0; rs[k] = 0.0; }
-  __syncthreads();
-  {
-    constexpr int NCH = (MAX_E + 63) / 64, RU = 11;
-    double colacc[NCH];
-#pragma unroll
-    for (int c = 0; c < NCH; ++c) colacc[c] = 0.0;
-    for (int i0 = wv; i0 < E; i0 += (NT / 64) * RU) {
-      float h[RU][NCH];
-#pragma unroll
-      for (int u = 0; u < RU; ++u) {
-        const int i = i0 + (NT / 64) * u;
-#pragma unroll
-        for (int c = 0; c < NCH; ++c) {
-          const int k = lane + 64 * c;
-          h[u][c] = (i < E && k < i) ? H[(size_t)i * ld + k] : 0.f;
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < RU; ++u) {
-        const int i = i0 + (NT / 64) * u;
-        const double xi = i < E ? (double)xvec[i] : 0.0;
-        double sd = 0.0;
-#pragma unroll
-        for (int c = 0; c < NCH; ++c) {
-          sd += (double)h[u][c] * (double)xvec[lane + 64 * c];
-          colacc[c] += (double)h[u][c] * xi;
-        }
-        sd = wave_sum(sd);
-        if (lane == 0 && i < E) rs[i] = sd;
-      }
+    // ---- solve L L^T x = b (fp32), then one refinement step with an fp64 residual from the fp32 system ----
+    for (int i = tid; i < NBK * 32; i += NT) {
+      rv[i] = i < E ? (aug ? Lg[(size_t)E * LGS + i] : bvec[i]) : 0.f;     // aug: y = row E of the bordered factor
+      xvec[i] = 0.f;
     }
-#pragma unroll
-    for (int c = 0; c < NCH; ++c)
-      if (lane + 64 * c < E) atomicAdd(&cs[lane + 64 * c], colacc[c]);
+    __syncthreads();
+    solve_packed(Lp, rv, E, tid, !aug);
+    if (trc) g_k5_trace[3] = clock64();
+    for (int i = tid; i < E; i += NT) xvec[i] = rv[i];
+    __syncthreads();
+    // r = b - A x in fp64 from the fp32 system.  Only the lower triangle of H is valid; one sweep over it with
+    // row-contiguous (coalesced) reads serves both halves of the symmetric product: element H[i][k] (k < i) adds
+    // H[i][k] x[k] to row i (wave reduction) and H[i][k] x[i] to column k (per-lane accumulators, merged with LDS fp64
+    // atomics at the end).  Eleven rows per wave (a third of its share) are in flight at a time to cover the load latency.
+    for (int k = tid; k < NBK * 32; k += NT) { cs[k] = k < E ? (double)diagA[k] * (double)xvec[k] : 0.0; rs[k] = 0.0; }
+    __syncthreads();
+    {
+      constexpr int NCH = (MAX_E + 63) / 64, RU = 11;
+      double colacc[NCH];
+  #pragma unroll
+      for (int c = 0; c < NCH; ++c) colacc[c] = 0.0;
+      for (int i0 = wv; i0 < E; i0 += (NT / 64) * RU) {
+        float h[RU][NCH];
+  #pragma unroll
+        for (int u = 0; u < RU; ++u) {
+          const int i = i0 + (NT / 64) * u;
+  #pragma unroll
+          for (int c = 0; c < NCH; ++c) {
+            const int k = lane + 64 * c;
+            h[u][c] = (i < E && k < i) ? H[(size_t)i * ld + k] : 0.f;
+          }
+        }
+  #pragma unroll
+        for (int u = 0; u < RU; ++u) {
+          const int i = i0 + (NT / 64) * u;
+          const double xi = i < E ? (double)xvec[i] : 0.0;
+          double sd = 0.0;
+  #pragma unroll
+          for (int c = 0; c < NCH; ++c) {
+            sd += (double)h[u][c] * (double)xvec[lane + 64 * c];
+            colacc[c] += (double)h[u][c] * xi;
+          }
+          sd = wave_sum(sd);
+          if (lane == 0 && i < E) rs[i] = sd;
+        }
+      }
+  #pragma unroll
+      for (int c = 0; c < NCH; ++c)
+        if (lane + 64 * c < E) atomicAdd(&cs[lane + 64 * c], colacc[c]);
+    }
+    __syncthreads();
+    for (int i = tid; i < E; i += NT) rv[i] = (float)((double)bvec[i] - (rs[i] + cs[i]));
+    __syncthreads();
+    if (trc) g_k5_trace[4] = clock64();
+    solve_packed(Lp, rv, E, tid);
+    if (trc) g_k5_trace[5] = clock64();
+    for (int i = tid; i < E; i += NT) xvec[i] += rv[i];
+    __syncthreads();
   }
-  __syncthreads();
-  for (int i = tid; i < E; i += NT) rv[i] = (float)((double)bvec[i] - (rs[i] + cs[i]));
-  __syncthreads();
-  if (trc) g_k5_trace[4] = clock64();
-  solve_packed(Lp, rv, E, tid);
-  if (trc) g_k5_trace[5] = clock64();
-  for (int i = tid; i < E; i += NT) xvec[i] += rv[i];
-  __syncthreads();
+  if (trc) { g_k5_trace[6] = clock64(); g_k5_trace[7] = cg_ok ? 1 : 0; }
   if (a.dbg_delta != nullptr)
     for (int i = tid; i < E; i += NT) a.dbg_delta[(size_t)b * ld + i] = xvec[i];
 

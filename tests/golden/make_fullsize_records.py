@@ -10,8 +10,9 @@ instances, in both pose modes, once on the nominal inputs and once per 1-ulp-siz
 records: per instance  |cd_gpu - cd_cpu| / cd_cpu <= max(1e-4, k * noise_i),  noise_i = the largest deviation of the
 perturbed oracle runs of that instance (the reference algorithm's own sensitivity to a 1e-7 relative input change).
 
-The 640 oracle runs take about 50 minutes on 8 cores (35 s each, one thread per run); partial results are kept under
-/tmp so the script can be resumed.  Usage:  python tests/golden/make_fullsize_records.py [n_instances] [n_iter]
+Sixteen perturbed runs per instance and mode (4 structured: points x(1+-1e-7), initial pose x(1+1e-7), fg depths
+x(1+1e-7); 12 with independent 1e-7-relative jitter of every point coordinate): 64 x 2 x 17 = 2176 oracle runs, about
+2.5 hours on 8 cores (35 s each, one thread per run); partial results are kept under /tmp so the script can be resumed.  Usage:  python tests/golden/make_fullsize_records.py [n_instances] [n_iter]
 """
 import os
 import sys
@@ -23,7 +24,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(HERE, "..", ".."))
 
 L, B_ALL = 256, 64
-PERTS = ("nominal", "points_up", "points_down", "pose0_up", "depth_up")
+N_JITTER = 12
+PERTS = ("nominal", "points_up", "points_down", "pose0_up", "depth_up") + tuple(f"points_jitter{k}" for k in range(N_JITTER))
 MODES = ("known", "free")
 EPS = 1e-7
 SCRATCH = "/tmp/c2_fullsize_records"
@@ -49,6 +51,11 @@ def perturb(d, which):
         d["T_ow0"] = T
     elif which == "depth_up":
         d["render"]["depth_fg"] = [(a * f32(1 + EPS)).astype(f32) for a in d["render"]["depth_fg"]]
+    elif which.startswith("points_jitter"):
+        # independent 1e-7-relative jitter of every coordinate (|u| <= 1), a different stream per variant
+        rs = np.random.RandomState(7000 + int(which[len("points_jitter"):]))
+        u = rs.uniform(-1.0, 1.0, d["points_w"].shape)
+        d["points_w"] = (d["points_w"].astype(np.float64) * (1.0 + EPS * u)).astype(f32)
     elif which != "nominal":
         raise ValueError(which)
     return d

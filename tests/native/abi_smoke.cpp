@@ -1,7 +1,8 @@
 // Stand-alone consumer of libhortihip.so: no Python, no torch -- only the public header, the HIP runtime for the
 // caller-owned device buffers, and the C ABI.  Builds an analytic decoder (every hidden unit i < 3 of layer 0 copies one
 // coordinate, the rest of the network passes it on), decodes a handful of points in both arithmetics and checks the
-// closed form  sdf = tanh(w * relu(x + y + z... ))  -- see the comments below.  Prints ABI_SMOKE_OK on success.
+// closed form  sdf = tanh(w * relu(x + y + z... ))  -- see the comments below -- and runs one Levenberg-Marquardt iteration of
+// hm_optimize_batch (shape-only mode) against ITS closed form.  Prints ABI_SMOKE_OK on success.
 #include <hip/hip_runtime.h>
 #include <cmath>
 #include <cstdio>
@@ -73,6 +74,61 @@ int main() {
   // a refused request must come back as an error code with a message, not a crash
   if (hm_decode_batch(dec, B, d_lat, L, d_pts, d_nq, 63, d_cb, d_y, d_J, ldJ, 7, 1, st) == 0) { printf("stride 63 accepted\n"); return 6; }
   if (hm_last_error() == nullptr || hm_last_error()[0] == 0) { printf("no error text\n"); return 7; }
+  // ---- hm_optimize_batch (mode 1 = Optimizer.shape_opt_deepsdf, optimizer.py:306-429) with a closed-form answer ----
+  // Points on the +x axis (y = z = 0), T_ow = identity, latent z0 > 0: sdf_i = tanh(0.5 x_i + 2 z0 + 0.1), only z0 has a
+  // non-zero Jacobian column J_i = 2 (1 - sdf_i^2).  One LM iteration (optimizer.py:362-397):
+  //   H = mean(J^2) + w_c,  b = -mean(J sdf) - w_c z0,  H += lambda_0 H,  z0 += b / H;   every other code entry stays 0.
+  {
+    HM(hm_decoder_set_precision(dec, 0));
+    const int NP = 100;
+    hm_limits lim = {1, NP, 0, 0, 0, 0};
+    hm_workspace_t ws = nullptr;
+    HM(hm_workspace_create(dec, &lim, &ws));
+    hm_opt_cfg cfg = {};
+    cfg.scale_on = 1; cfg.robust_iter = 5; cfg.lm_on = 1; cfg.lm_eye = 0; cfg.lm_lambda_0 = 0.1f; cfg.s_damp = 1e-3f;
+    cfg.recon_robust_th = 0.01f; cfg.render_robust_th = 0.05f; cfg.n_sample_on_ray = 16; cfg.log_sdf_occ = 1;
+    cfg.occ_cutoff = 0.01f; cfg.occlusion_on = 1; cfg.w_recon = 1.f; cfg.w_depth = 0.05f; cfg.w_mask = 5e-4f;
+    cfg.w_codereg = 5e-4f; cfg.max_iter = 1; cfg.occlusion_th = 0.03f; cfg.min_valid_sample = 100; cfg.min_grad_thre = 1e-6f;
+    std::vector<float> pw((size_t)NP * 3, 0.f), z(L, 0.f), T(16, 0.f);
+    for (int i = 0; i < NP; ++i) pw[(size_t)i * 3] = 0.01f * (i + 1);
+    z[0] = 0.3f;
+    T[0] = T[5] = T[10] = T[15] = 1.f;
+    float *d_pw, *d_z, *d_T; int *d_np, *d_it, *d_st;
+    CK(hipMalloc(&d_pw, pw.size() * 4)); CK(hipMalloc(&d_z, L * 4)); CK(hipMalloc(&d_T, 64));
+    CK(hipMalloc(&d_np, 4)); CK(hipMalloc(&d_it, 4)); CK(hipMalloc(&d_st, 4));
+    CK(hipMemcpy(d_pw, pw.data(), pw.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(d_z, z.data(), L * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(d_T, T.data(), 64, hipMemcpyHostToDevice));
+    CK(hipMemcpy(d_np, &NP, 4, hipMemcpyHostToDevice));
+    hm_batch bt = {};
+    bt.B = 1; bt.points_stride = NP; bt.d_points_w = d_pw; bt.d_n_points = d_np; bt.d_latent = d_z; bt.d_T_ow = d_T;
+    bt.d_iter_count = d_it; bt.d_status = d_st;
+    HM(hm_optimize_batch(ws, &cfg, &bt, 1, nullptr, st));
+    CK(hipStreamSynchronize(st));
+    std::vector<float> zo(L);
+    int it = -1, stt = -1;
+    CK(hipMemcpy(zo.data(), d_z, L * 4, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(&it, d_it, 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(&stt, d_st, 4, hipMemcpyDeviceToHost));
+    double sJJ = 0, sJr = 0;
+    for (int i = 0; i < NP; ++i) {
+      const double y = std::tanh(0.5 * (double)pw[(size_t)i * 3] + 2.0 * 0.3 + 0.1), J = 2.0 * (1.0 - y * y);
+      sJJ += J * J; sJr += J * y;
+    }
+    const double Hd = (sJJ / NP + 5e-4) * 1.1, bd = -sJr / NP - 5e-4 * 0.3, want = 0.3 + bd / Hd;
+    if (it != 1 || stt != HM_STATUS_MAX_ITER || std::fabs(zo[0] - want) > 2e-6 * std::fabs(want)) {
+      printf("optimize mismatch: iter %d status %d z0 %.8f want %.8f\n", it, stt, zo[0], want);
+      return 8;
+    }
+    for (int i = 1; i < L; ++i) if (zo[i] != 0.f) { printf("latent entry %d moved: %g\n", i, zo[i]); return 9; }
+    // an instance that exceeds the packed stride is refused per instance, not truncated
+    const int too_many = NP + 1;
+    CK(hipMemcpy(d_np, &too_many, 4, hipMemcpyHostToDevice));
+    HM(hm_optimize_batch(ws, &cfg, &bt, 1, nullptr, st));
+    CK(hipStreamSynchronize(st));
+    CK(hipMemcpy(&stt, d_st, 4, hipMemcpyDeviceToHost));
+    if (stt != HM_STATUS_LIMIT) { printf("oversized instance not flagged: status %d\n", stt); return 10; }
+    HM(hm_workspace_destroy(ws));
+  }
   HM(hm_decoder_destroy(dec));
   printf("ABI_SMOKE_OK\n");
   return 0;

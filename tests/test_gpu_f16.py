@@ -46,7 +46,8 @@ def test_f16_decoder_vs_fp64_oracle_ragged_tiles(L):
             gx = J[b, :k, L:L + 3] if pose_dim == 0 else J[b, :k, L:L + 3]
             assert float((gx - go[:, L:]).abs().max()) < 2e-2 * float(go[:, L:].abs().max())
             assert float((J[b, :k, L + 7] - y[b, :k]).abs().max()) == 0.0      # residual column = sdf
-            assert float(J[b, k:].abs().max()) == 0.0 and float(y[b, k:].abs().max()) == 0.0   # padding untouched
+            if k < N:
+                assert float(J[b, k:].abs().max()) == 0.0 and float(y[b, k:].abs().max()) == 0.0   # padding untouched
 
 
 def test_f16_optimisation_runs_and_is_batch_invariant():

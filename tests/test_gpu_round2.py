@@ -110,3 +110,38 @@ def test_from_module_with_weight_norm_hooks_and_cache_invalidation():
         net.lin8.bias.add_(0.5)
     y1 = U.decode_sdf(net, z, x).cpu().numpy()
     assert np.abs(np.arctanh(np.clip(y1, -0.999999, 0.999999)) - np.arctanh(y0) - 0.5).max() < 1e-3
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+def test_solver_fast_path_and_direct_fallback_agree(precision, monkeypatch):
+    """The solve kernel has two paths: Jacobi-preconditioned CG (taken when it reaches a 1e-7 relative residual, which
+    the damped systems of the shipped configurations do in ~25 iterations) and the blocked Cholesky + fp64-refined
+    triangular solves it falls back to.  Both must reproduce the reference's step (G8: delta <= 2e-4 vs its fp32
+    inverse, <= 5e-5 vs the fp64 oracle) and the golden trajectories; HM_FORCE_DIRECT_SOLVE=1 selects the fallback."""
+    from hortimapping_amd import optimizer as HO
+    from hortimapping_amd.decoder import DecoderWeights
+    from oracle import hm_oracle as O
+    out = {}
+    for forced in ("0", "1"):
+        monkeypatch.setenv("HM_FORCE_DIRECT_SOLVE", forced)
+        g = GU.load("g8_one_iter_pepper256")
+        dec = DecoderWeights.from_params(GU.decoder_params("pepper256")).set_precision(precision)
+        cfg = GU.cfg_from_golden(g)
+        inst = HO.Instance(torch.from_numpy(g["z0"]), torch.from_numpy(g["T_ow0"]), torch.from_numpy(g["points_w"]),
+                           GU.render_data_from_golden(g), float(g["cube_radius"]), False)
+        dbg = {}
+        HO.optimize_batch(dec, cfg, [inst], debug=dbg)
+        L = 256
+        perm = list(range(L, L + 7)) + list(range(L))
+        d = dbg["delta"][0].cpu().numpy()[perm]
+        assert GU.relmax(d, g["delta_free"]) < 2e-4
+        out[forced] = d
+        for name in ("g9_traj_known_sim3_it20", "g9_traj_exit_code", "g9_traj_known_gn_it3", "g9_traj_sdf_it20"):
+            t = GU.load(name)
+            dec32 = DecoderWeights.from_params(GU.decoder_params(str(t["decoder"]))).set_precision(precision)
+            it = HO.Instance(torch.from_numpy(t["latent0"]), torch.from_numpy(t["T_ow0"]), torch.from_numpy(t["points_w"]),
+                             GU.render_data_from_golden(t), float(t["cube_radius"]), bool(t["pose_known"]))
+            r = HO.optimize_batch(dec32, GU.cfg_from_golden(t), [it], shape_only=(str(t["kind"]) == "sdf"))[0]
+            assert r.iter_count == int(t["iter_count"]), (name, forced)
+            assert GU.relmax(r.latent, t["z_out"]) < 1e-3 and GU.relmax(r.T_ow, t["T_out"]) < 1e-4, (name, forced)
+    assert GU.relmax(out["0"], out["1"]) < 2e-5          # the two solvers agree far inside the reference's own rounding
