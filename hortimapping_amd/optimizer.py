@@ -10,6 +10,7 @@ from __future__ import annotations
 
 import ctypes
 import functools
+import os
 from dataclasses import dataclass
 from typing import List, Optional, Sequence
 
@@ -213,7 +214,7 @@ class PackedBatch:
         B = len(instances)
         self.B = B
         f32, i32 = torch.float32, torch.int32
-        pin = torch.cuda.is_available()
+        pin = torch.cuda.is_available() and os.environ.get("HM_PIN", "1") != "0"
 
         def host(*shape, dtype=f32):
             return torch.zeros(*shape, dtype=dtype, pin_memory=pin)

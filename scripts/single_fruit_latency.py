@@ -27,6 +27,7 @@ for prec in ("f32", "f16x3"):
             z, T, n = opt.shape_pose_joint_opt(inst.latent.clone(), inst.T_ow, inst.render_data, inst.points_w,
                                                inst.cube_radius, None)
             torch.cuda.synchronize(); times.append(time.perf_counter() - t0); iters.append(n)
+    print(prec, " ".join(f"{1e3*t:.1f}" for t in times), file=sys.stderr)
     first, rest = times[0], np.array(times[1:])
     out[prec] = {"first_call_ms": round(1e3 * first, 1), "later_calls_ms_median": round(1e3 * float(np.median(rest)), 1),
                  "later_calls_ms_min_max": [round(1e3 * float(rest.min()), 1), round(1e3 * float(rest.max()), 1)],

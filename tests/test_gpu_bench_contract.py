@@ -33,3 +33,21 @@ def test_bench_json_contract():
     c = d["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] and c["sample"]
     assert abs(d["value"] - 4 * 2 / (d["ms_per_step"] * 2 * 1e-3)) < 0.02 * d["value"]     # value = units / time
+
+
+def test_bench_strong_scaling_configs3_rank_share():
+    """BASELINE.json configs[3] as one rank of eight sees it: 512 instances at the benchmark size (L = 256, 1024 surface
+    points + 64 rays x 16 samples) through ONE workspace in two chunks of 256, `bench.py --total` (the full job is
+    --total 4096 over 8 GPUs; the iteration count is cut to keep the test short)."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "0",
+                          "--total", "512", "--batch", "256", "--iters", "6", "--no-exact", "--no-cpu-baseline"],
+                         capture_output=True, text=True, timeout=1200, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["scaling"] == "strong" and d["n_gpus"] == 1 and d["value"] > 0
+    c = d["config"]
+    assert c["instances_total"] == 512 and c["instances_per_gpu"] == 512 and c["chunk"] == 256 and c["iterations"] == 6
+    assert abs(d["value"] - 512 / (d["ms_per_step"] * 1e-3)) < 0.02 * d["value"]
+    assert d["roofline"]["launches"] == 2 * 6                          # two chunks x six iterations were profiled
