@@ -146,11 +146,21 @@ def parse_args(argv=None):
     ap.add_argument("--no-exact", action="store_true", help="skip the extra exact-fp32 / mixed-precision steps")
     ap.add_argument("--precision", default=os.environ.get("HM_PRECISION", "f16x3"), choices=sorted(PRECISIONS),
                     help="decoder GEMM arithmetic of the primary line")
+    ap.add_argument("--decoder", default="analytic", choices=["analytic", "trained"],
+                    help="decoder weights: the analytic synthetic fruit (default, BASELINE workload) or the weights learnt "
+                         "by scripts/train_synthetic_deepsdf.py (tests/golden/trained_decoder_L256.npz, L = 256 only)")
     ap.add_argument("--stub-cpu", action="store_true", help=argparse.SUPPRESS)
     return ap.parse_args(argv)
 
 
-def main(argv=None):
+def load_trained_decoder():
+    """Weights + learnt codes of the trained decoder (dense 512 x 512 layers; a committed fixture, see its generator)."""
+    import numpy as np
+    with np.load(os.path.join(ROOT, "tests", "golden", "trained_decoder_L256.npz")) as f:
+        return {k: (int(f[k]) if k in ("latent_dim", "hidden") else f[k]) for k in f.files}
+
+
+def main(argv=None, emit=True):
     args = parse_args(argv)
     from hortimapping_amd import distributed as D
     import torch.distributed as dist
@@ -194,7 +204,11 @@ def main(argv=None):
     else:
         from hortimapping_amd import _lib, synthetic as S, workloads as W, optimizer as HO
         from hortimapping_amd.decoder import DecoderWeights
-        params = S.make_synthetic_decoder(L, seed=2, r0=0.04, aniso=(1.0, 0.75, 1.3))
+        if args.decoder == "trained":
+            assert L == 256, "the trained decoder fixture has a 256-dim latent"
+            params = load_trained_decoder()
+        else:
+            params = S.make_synthetic_decoder(L, seed=2, r0=0.04, aniso=(1.0, 0.75, 1.3))
         dec = DecoderWeights.from_params(params)
         cfg = W.c2_opt_cfg(max_iter=args.iters, n_sample_on_ray=16, n_frame=1)
         hcfg = HO.opt_cfg_from_dict(cfg)
@@ -270,16 +284,20 @@ def main(argv=None):
         q = (sum(int(p.n_points.sum().item()) for p in pbs) / len(pbs)) if queries_per_launch is None else queries_per_launch
         flops = q * FLOP_FWD_BWD
         achieved = flops / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
-        traffic, tsrc = None, None    # HBM/fabric bytes per launch: from committed PMC passes of the same workload
+        traffic, tsrc, busy = None, None, None    # HBM/fabric bytes per launch: from committed PMC passes of the same workload
         tj = os.path.join(ROOT, TRAFFIC_FILE)
-        if kind == "joint" and not strong and per_gpu == 64 and L == 256 and os.path.exists(tj):
-            traffic = json.load(open(tj)).get(precision, {}).get("bytes_per_launch")
+        if kind == "joint" and not strong and per_gpu == 64 and L == 256 and args.decoder == "analytic" and os.path.exists(tj):
+            tj_ = json.load(open(tj)).get(precision, {})
+            traffic, busy = tj_.get("bytes_per_launch"), tj_.get("mfma_pipe_busy_frac")
             if traffic is not None:
                 tsrc = f"{TRAFFIC_FILE} (rocprofv3 PMC passes of the same workload, committed; NOT measured in this run)"
         r = {"bound": "mfma", "kernel": kname + " (SDF-term decoder forward + input-gradient backward)",
              "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
              "traffic": traffic, "traffic_source": tsrc, "launches": n_launch, "avg_launch_ms": round(avg_ms, 4),
              "algorithmic_flop_per_launch": int(flops)}
+        if busy is not None:                      # matrix-pipe utilisation (all MFMA issued, incl. the 3 passes of f16x3)
+            r["mfma_pipe_busy_frac"] = busy
+            r["mfma_pipe_busy_source"] = tsrc
         if precision == "f16x3":
             r["note"] = ("achieved counts ALGORITHMIC flop (dense fp32 decoder); the split-operand kernel issues 3 fp16 "
                          "MFMA passes per product, so its ceiling is 1/3 of the fp16 peak")
@@ -316,6 +334,9 @@ def main(argv=None):
                 "workload": head + ", " + (joint_txt if kind == "joint" else sdf_txt),
                 "instances_total": n_total, "instances_per_gpu": n_local, "chunk": chunk if strong else per_gpu,
                 "latent_dim": L, "iterations": args.iters, "precision": args.precision,
+                "decoder_weights": ("analytic synthetic fruit (hortimapping_amd/synthetic.py)" if args.decoder == "analytic" else
+                                    "trained on a synthetic pepper family (scripts/train_synthetic_deepsdf.py, "
+                                    "tests/golden/trained_decoder_L256.npz)"),
                 "parallelism": f"instances sharded over {world} GPU(s), one RCCL all-gather of results per step",
             },
         }
@@ -337,10 +358,21 @@ def main(argv=None):
                         "max_abs_T_diff_vs_primary": float((T2 - T).abs().max()),
                         "diff_note": "free-pose 200-iteration trajectories amplify rounding noise; per-instance parity of "
                                      "every arithmetic vs the CPU oracle: profiles/r02_parity_fullsize_*.txt"}
+    if (not stub and not args.no_exact and world == 1 and not strong and args.decoder == "analytic" and L == 256
+            and kind == "joint" and per_gpu == 64):
+        # the same job on TRAINED decoder weights (dense layers instead of the near-identity analytic ones: different
+        # operand statistics for the matrix cores and the socket power limit), one timed step
+        o2 = main(["--steps", "1", "--warmup", "1", "--iters", str(args.iters), "--decoder", "trained", "--precision",
+                   args.precision, "--no-exact", "--no-cpu-baseline"], emit=False)
+        out["trained_decoder"] = {"value": o2["value"], "unit": o2["unit"], "steps": 1, "dtype": o2["dtype"],
+                                  "ms_per_step": o2["ms_per_step"], "roofline": o2["roofline"],
+                                  "decoder_weights": o2["config"]["decoder_weights"],
+                                  "parity": "profiles/r02_parity_trained_*.txt (per-instance vs the CPU oracle)"}
     if rank == 0:
         if not stub and not args.no_cpu_baseline and world == 1:   # N = 1 only; other ranks would idle in the barrier
             out["cpu_baseline"] = cpu_baseline(params, cfg, dicts[0], kind)
-        print(json.dumps(out), flush=True)
+        if emit:
+            print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

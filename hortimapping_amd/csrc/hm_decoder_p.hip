@@ -92,7 +92,14 @@ __device__ __forceinline__ void step_p(f32x16 (&acc)[NRB][NQB], const ASetP& a, 
 
 template <bool U0, bool U1>
 __device__ __forceinline__ void gemm_loop_p(f32x16 (&acc)[NRB][NQB], const f16x8* __restrict__ wp0,
-                                            const f16x8* __restrict__ wp1, int n_k16, const f16x8* xp, int lane) {
+                                            const f16x8* __restrict__ wp1, int n_k16, const f16x8* xp, int lane_) {
+  // The lane id is re-derived HERE (volatile asm: not CSE'd with the kernel's copy) so that the LDS read pointer of the
+  // loop is computed in its preheader instead of being reloaded from a spill slot: a scratch reload still in flight
+  // at loop entry makes hipcc's wait-count pass put s_waitcnt vmcnt(0) in front of the first ds_read of EVERY
+  // iteration, which drains the weight prefetch ring (effective prefetch distance: one K-step).
+  int lane;
+  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
+  (void)lane_;
   const int xo = (lane >> 5) * TQP + (lane & 31);
   const int last = n_k16 - 1;
   ASetP a0 = {}, a1 = {}, a2 = {};

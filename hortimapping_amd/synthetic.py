@@ -174,7 +174,7 @@ def _first_hit(sdf_fn, origins, dirs, t0, t1, n_march=48, n_bisect=18):
 
 def make_instance(Ws, bs, latent_dim, inst_id, n_pts=2048, n_frames=1, n_fg=32, n_bg=32,
                   seed_base=1000, r_max=0.08, sdf_fn_factory=None, z_sigma=0.07,
-                  pose_noise=0.005, pix_halfwidth=80.0, scale_init=1.0):
+                  pose_noise=0.005, pix_halfwidth=80.0, scale_init=1.0, z_true=None):
     """One synthetic fruit instance in the reference's caller-side data format.
 
     Returns a dict with fp32 arrays: ``latent0 (L,)``, ``T_ow0 (4,4)``, ``points_w (n_pts,3)``,
@@ -184,11 +184,14 @@ def make_instance(Ws, bs, latent_dim, inst_id, n_pts=2048, n_frames=1, n_fg=32, 
     generating truth (``z_true``, ``T_wo_true``) for Chamfer/pose-error metrics.
 
     ``sdf_fn_factory(z)`` may supply an accelerated ``x -> sdf`` callable; default is the
-    numpy forward above.
+    numpy forward above.  ``z_true`` overrides the Gaussian draw of the generating latent (used with trained
+    decoders, whose plausible shapes sit near their learnt codes); the draw is still consumed so that the
+    remaining stream does not move.
     """
     L = int(latent_dim)
     rs = np.random.RandomState(seed_base + int(inst_id))
-    z_true = (z_sigma * rs.randn(L)).astype(np.float32)
+    z_draw = (z_sigma * rs.randn(L)).astype(np.float32)
+    z_true = z_draw if z_true is None else np.asarray(z_true, dtype=np.float32).reshape(L)
     centre = rs.uniform(-0.01, 0.01, 3) + np.array([0.0, 0.0, 0.5])
     if sdf_fn_factory is None:
         def sdf_obj(p):

@@ -51,17 +51,30 @@ def gpu_sdf_factory(dec: DecoderWeights, device="cuda"):
     return factory
 
 
+def trained_z_true(params, i):
+    """Generating latent of instance i for a TRAINED decoder (`scripts/train_synthetic_deepsdf.py`): a point a quarter
+    of the way between two of its learnt codes, picked by a per-instance stream -- a plausible shape that is none of the
+    training shapes and (unlike a midpoint) not close to the mean shape the optimisation starts from."""
+    codes = np.asarray(params["codes"], dtype=np.float32)
+    a, b = np.random.RandomState(3000 + int(i)).choice(codes.shape[0], 2, replace=False)
+    return 0.75 * codes[a] + 0.25 * codes[b]
+
+
 def make_c2_instances(params, dec, ids, kind="joint", device="cuda"):
-    """C2-joint: 1024 surface points + 1 frame x (32 fg + 32 bg) rays; C2-sdf: 2048 surface points, no rays."""
+    """C2-joint: 1024 surface points + 1 frame x (32 fg + 32 bg) rays; C2-sdf: 2048 surface points, no rays.  A params
+    dict that carries learnt `codes` (a trained decoder) draws its generating latents from them."""
     Ws, bs = S.fold_weight_norm(params)
     L = int(params["latent_dim"])
     fac = gpu_sdf_factory(dec, device) if (dec is not None and torch.cuda.is_available()) else None
     out = []
     for i in ids:
+        zt = trained_z_true(params, i) if "codes" in params else None
         if kind == "joint":
-            d = S.make_instance(Ws, bs, L, i, n_pts=1024, n_frames=1, n_fg=32, n_bg=32, sdf_fn_factory=fac)
+            d = S.make_instance(Ws, bs, L, i, n_pts=1024, n_frames=1, n_fg=32, n_bg=32, sdf_fn_factory=fac, z_true=zt)
         else:
-            d = S.make_instance(Ws, bs, L, i, n_pts=2048, n_frames=1, n_fg=4, n_bg=4, sdf_fn_factory=fac)
+            d = S.make_instance(Ws, bs, L, i, n_pts=2048, n_frames=1, n_fg=4, n_bg=4, sdf_fn_factory=fac, z_true=zt)
+        if zt is not None:                       # start from the mean learnt code, as `test_wild_completion.py:46-47` does
+            d["latent0"] = np.asarray(params["codes"], dtype=np.float32).mean(0)
         out.append(d)
     return out
 

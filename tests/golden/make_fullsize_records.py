@@ -12,7 +12,12 @@ perturbed oracle runs of that instance (the reference algorithm's own sensitivit
 
 Sixteen perturbed runs per instance and mode (4 structured: points x(1+-1e-7), initial pose x(1+1e-7), fg depths
 x(1+1e-7); 12 with independent 1e-7-relative jitter of every point coordinate): 64 x 2 x 17 = 2176 oracle runs, about
-2.5 hours on 8 cores (35 s each, one thread per run); partial results are kept under /tmp so the script can be resumed.  Usage:  python tests/golden/make_fullsize_records.py [n_instances] [n_iter]
+2.5 hours on 8 cores (35 s each, one thread per run); partial results are kept under /tmp so the script can be resumed.
+
+The same records for the TRAINED decoder (`tests/golden/trained_decoder_L256.npz`, weights learnt by
+`scripts/train_synthetic_deepsdf.py`): 16 instances x 2 modes x 9 runs -> trained_c2_inputs.npz / trained_c2_oracle.npz.
+
+Usage:  python tests/golden/make_fullsize_records.py [n_instances] [n_iter] [analytic|trained] [n_jitter]
 """
 import os
 import sys
@@ -24,15 +29,20 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(HERE, "..", ".."))
 
 L, B_ALL = 256, 64
-N_JITTER = 12
+DECODER = sys.argv[3] if len(sys.argv) > 3 else "analytic"
+N_JITTER = int(sys.argv[4]) if len(sys.argv) > 4 else 12
 PERTS = ("nominal", "points_up", "points_down", "pose0_up", "depth_up") + tuple(f"points_jitter{k}" for k in range(N_JITTER))
 MODES = ("known", "free")
 EPS = 1e-7
-SCRATCH = "/tmp/c2_fullsize_records"
+SCRATCH = "/tmp/c2_fullsize_records" if DECODER == "analytic" else "/tmp/c2_trained_records"
+PREFIX = "c2_fullsize" if DECODER == "analytic" else "trained_c2"
 
 
 def decoder_params():
     from hortimapping_amd import synthetic as S
+    if DECODER == "trained":
+        with np.load(os.path.join(HERE, "trained_decoder_L256.npz")) as f:
+            return {k: (int(f[k]) if k in ("latent_dim", "hidden") else f[k]) for k in f.files}
     return S.make_synthetic_decoder(L, seed=2, r0=0.04, aniso=(1.0, 0.75, 1.3))
 
 
@@ -120,7 +130,7 @@ def main():
     inst = [np.load(os.path.join(SCRATCH, f"inst_{i:03d}.npz")) for i in range(n_inst)]
     keys = ("latent0", "T_ow0", "points_w", "T_wc", "rays_fg", "rays_bg", "depth_fg", "depth_bg", "cube_radius",
             "z_true", "T_wo_true")
-    np.savez_compressed(os.path.join(HERE, "c2_fullsize_inputs.npz"),
+    np.savez_compressed(os.path.join(HERE, PREFIX + "_inputs.npz"),
                         **{k: np.stack([np.asarray(a[k]) for a in inst]) for k in keys})
     rec = {}
     for m in MODES:
@@ -132,7 +142,7 @@ def main():
                 r = np.load(os.path.join(SCRATCH, f"{i:03d}_{m}_{p}_{n_iter}.npz"))
                 lat[pi, i], Tow[pi, i], itc[pi, i] = r["latent"], r["T_ow"], r["iter_count"]
         rec[f"{m}_latent"], rec[f"{m}_T_ow"], rec[f"{m}_iter_count"] = lat, Tow, itc
-    np.savez_compressed(os.path.join(HERE, "c2_fullsize_oracle.npz"), perts=np.array(PERTS), n_iter=n_iter,
+    np.savez_compressed(os.path.join(HERE, PREFIX + "_oracle.npz"), perts=np.array(PERTS), n_iter=n_iter,
                         eps=EPS, **rec)
     print("written", flush=True)
 

@@ -94,18 +94,30 @@ K_OUTLIER = 6.0
 _FS = {}
 
 
-def fullsize_fixture():
+RECORDS = {"analytic": "c2_fullsize", "trained": "trained_c2"}      # record set -> fixture prefix under tests/golden/
+
+
+def trained_params():
+    """The decoder learnt by scripts/train_synthetic_deepsdf.py (dense layers, weight-norm g / v, 256 latent codes)."""
+    import os
+    from golden_util import GOLDEN_DIR
+    with np.load(os.path.join(GOLDEN_DIR, "trained_decoder_L256.npz")) as f:
+        return {k: (int(f[k]) if k in ("latent_dim", "hidden") else f[k]) for k in f.files}
+
+
+def fullsize_fixture(which="analytic"):
     """Inputs, oracle records and the per-instance metrics of the oracle runs (computed once per session with ONE
     sampler for every party: the exact-fp32 GPU decoder along 2000 Fibonacci directions, metrics.py)."""
-    if _FS:
-        return _FS
+    if which in _FS:
+        return _FS[which]
     import os
     from hortimapping_amd import metrics as MX, ops, synthetic as S
     from hortimapping_amd.decoder import DecoderWeights
     from golden_util import GOLDEN_DIR
-    inp = np.load(os.path.join(GOLDEN_DIR, "c2_fullsize_inputs.npz"))
-    rec = np.load(os.path.join(GOLDEN_DIR, "c2_fullsize_oracle.npz"))
-    params = S.make_synthetic_decoder(L, seed=2, r0=0.04, aniso=(1.0, 0.75, 1.3))
+    inp = np.load(os.path.join(GOLDEN_DIR, RECORDS[which] + "_inputs.npz"))
+    rec = np.load(os.path.join(GOLDEN_DIR, RECORDS[which] + "_oracle.npz"))
+    params = trained_params() if which == "trained" else S.make_synthetic_decoder(L, seed=2, r0=0.04, aniso=(1.0, 0.75, 1.3))
+    fs = {}
     sampler = DecoderWeights.from_params(params)
     sampler.set_precision("f32")
     dirs = torch.from_numpy(MX.fibonacci_dirs(2000)).float().cuda()
@@ -134,22 +146,23 @@ def fullsize_fixture():
         for i in range(len(latents)):
             T_wo = np.linalg.inv(np.asarray(T_ows[i], dtype=np.float64))
             pw = P[i] @ T_wo[:3, :3].T + T_wo[:3, 3]
-            out[i, 0] = MX.chamfer_distance(pw, _FS["gt"][i])
+            out[i, 0] = MX.chamfer_distance(pw, fs["gt"][i])
             out[i, 1:] = MX.pose_error(np.asarray(T_ows[i]), inp["T_wo_true"][i])
         return out
     n = inp["latent0"].shape[0]
     Pgt = level_sets(inp["z_true"])
-    _FS["gt"] = [Pgt[i] @ inp["T_wo_true"][i][:3, :3].astype(np.float64).T + inp["T_wo_true"][i][:3, 3] for i in range(n)]
-    _FS.update(inp=inp, rec=rec, metrics=metrics, n=n, params=params, oracle={})
+    fs["gt"] = [Pgt[i] @ inp["T_wo_true"][i][:3, :3].astype(np.float64).T + inp["T_wo_true"][i][:3, 3] for i in range(n)]
+    fs.update(inp=inp, rec=rec, metrics=metrics, n=n, params=params, oracle={})
     for mode in ("known", "free"):
-        _FS["oracle"][mode] = np.stack([metrics(rec[f"{mode}_latent"][p], rec[f"{mode}_T_ow"][p])
+        fs["oracle"][mode] = np.stack([metrics(rec[f"{mode}_latent"][p], rec[f"{mode}_T_ow"][p])
                                         for p in range(rec[f"{mode}_latent"].shape[0])])     # (perts, n, 4)
-    return _FS
+    _FS[which] = fs
+    return fs
 
 
-def fullsize_instances(pose_known):
+def fullsize_instances(pose_known, which="analytic"):
     from hortimapping_amd import optimizer as HO
-    inp = fullsize_fixture()["inp"]
+    inp = fullsize_fixture(which)["inp"]
     t = torch.from_numpy
     return [HO.Instance(t(inp["latent0"][i].copy()), t(inp["T_ow0"][i].copy()), t(inp["points_w"][i]),
                         {"T_wc": [t(inp["T_wc"][i])], "rays_fg": [t(inp["rays_fg"][i])], "rays_bg": [t(inp["rays_bg"][i])],
@@ -157,9 +170,12 @@ def fullsize_instances(pose_known):
                         float(inp["cube_radius"][i]), pose_known) for i in range(inp["latent0"].shape[0])]
 
 
+@pytest.mark.parametrize("records", ["analytic", "trained"])
 @pytest.mark.parametrize("mode", ["known", "free"])
-def test_full_batch_metric_parity(mode, precision):
-    """For EVERY one of the 64 c2_joint instances after 200 iterations:
+def test_full_batch_metric_parity(mode, precision, records):
+    """`records` = "analytic": the 64 c2_joint instances of the bench (analytic decoder, 16 perturbed oracle runs each);
+    "trained": 16 instances of the same workload on the TRAINED decoder (dense layers, 8 perturbed runs each).
+    For EVERY instance after 200 iterations:
         |m_gpu - m_cpu| <= max(1e-4 * scale(m_cpu), K_NOISE * noise_i)        m = Chamfer-to-GT, pose errors
     with noise_i = the largest deviation of the sixteen perturbed oracle runs of instance i from its nominal run (the
     reference algorithm's own response to a 1e-7 relative input change).  The two fp32-class arithmetics (f32, f16x3)
@@ -169,12 +185,12 @@ def test_full_batch_metric_parity(mode, precision):
     import os
     from hortimapping_amd import optimizer as HO, workloads as W
     from hortimapping_amd.decoder import DecoderWeights
-    fs = fullsize_fixture()
+    fs = fullsize_fixture(records)
     n = fs["n"]
     n_iter = int(fs["rec"]["n_iter"])
     dec = DecoderWeights.from_params(fs["params"])
     dec.set_precision(precision)
-    res = HO.optimize_batch(dec, W.c2_opt_cfg(max_iter=n_iter), fullsize_instances(mode == "known"))
+    res = HO.optimize_batch(dec, W.c2_opt_cfg(max_iter=n_iter), fullsize_instances(mode == "known", records))
     assert all(r.iter_count == n_iter and r.status == 8 for r in res)
     assert np.array_equal(fs["rec"][f"{mode}_iter_count"], np.full_like(fs["rec"][f"{mode}_iter_count"], n_iter))
     m_gpu = fs["metrics"](torch.stack([r.latent for r in res]).numpy(), [r.T_ow.numpy() for r in res])
@@ -187,7 +203,8 @@ def test_full_batch_metric_parity(mode, precision):
     tol_out = np.maximum(REL_FLOOR * scale, K_OUTLIER * noise)
     dev = np.abs(m_gpu - m_cpu)
     names = ("chamfer", "t_err", "r_err", "scale")
-    lines = [f"# c2_joint full batch, {n} instances x {n_iter} LM iterations, pose_{mode}, GPU {precision} vs CPU oracle",
+    lines = [f"# c2_joint full batch ({records} decoder), {n} instances x {n_iter} LM iterations, pose_{mode}, GPU {precision} "
+             "vs CPU oracle",
              f"# tolerance per instance and metric: max({REL_FLOOR:g} * scale, {K_NOISE:g} * noise_i); noise_i = max deviation "
              f"of {m_pert.shape[0]} perturbed oracle runs (points x(1+-1e-7), T_ow0 x(1+1e-7), depth_fg x(1+1e-7), "
              "independent 1e-7 jitters of every point coordinate)",
@@ -207,10 +224,43 @@ def test_full_batch_metric_parity(mode, precision):
     lines.append(f"# instances within 1e-4 relative Chamfer outright: {(relcd <= 1e-4).sum()} of {n}; failing the gate: "
                  f"{[b[0] for b in bad]}")
     os.makedirs("gpurun_out", exist_ok=True)
-    with open(os.path.join("gpurun_out", f"r02_parity_fullsize_{mode}_{precision}.txt"), "w") as f:
+    tag = "fullsize" if records == "analytic" else records
+    with open(os.path.join("gpurun_out", f"r02_parity_{tag}_{mode}_{precision}.txt"), "w") as f:
         f.write("\n".join(lines) + "\n")
     print("\n".join(lines[-2:]))
     if precision in ("f32", "f16x3"):          # the fp32-class arithmetics are gated; the other modes are reported
         assert len(bad) <= N_OUTLIER, f"{precision} pose_{mode}: instances outside max(1e-4, {K_NOISE} x noise): {bad}"
         for i, _ in bad:
             assert bool((dev[i] <= tol_out[i]).all()), f"{precision} pose_{mode}: instance {i} beyond {K_OUTLIER} x noise"
+
+
+def test_trained_decoder_vs_fp64_oracle(precision):
+    """SDF values and input gradients of the TRAINED decoder (dense 512 x 512 layers with learnt weight-norm gains, see
+    scripts/train_synthetic_deepsdf.py) against the fp64 oracle, at the learnt codes, on queries around the zero level
+    set: the two fp32-class arithmetics to fp32 rounding level, the labelled reduced modes to fp16 level; hidden
+    activations stay far inside the fp16 range (the guard would poison the outputs with NaN otherwise)."""
+    from hortimapping_amd import ops
+    from hortimapping_amd.decoder import DecoderWeights
+    from oracle import hm_oracle as O
+    tol_y, tol_j = {"f32": (2e-6, 2e-5), "f16x3": (2e-6, 2e-5), "f16x3f_f16b": (2e-6, 5e-3), "f16": (3e-4, 2e-2)}[precision]
+    p = trained_params()
+    od = O.fold_decoder(p).to(torch.float64)
+    dec = DecoderWeights.from_params(p)
+    dec.set_precision(precision)
+    codes = torch.from_numpy(p["codes"])
+    gen = torch.Generator().manual_seed(3)
+    B, n = 4, 448
+    lat = codes[torch.randperm(codes.shape[0], generator=gen)[:B]].contiguous()
+    d = torch.nn.functional.normalize(torch.randn(B, n, 3, generator=gen), dim=-1)
+    pts = d * (0.035 + 0.01 * torch.randn(B, n, 1, generator=gen))
+    pts4 = torch.zeros(B, n, 4)
+    pts4[..., :3] = pts
+    y, J = ops.decode_batch(dec, lat.cuda(), pts4.cuda(), torch.full((B,), n, dtype=torch.int32).cuda(), mode=1, pose_dim=0)
+    y, J = y.cpu().double(), J.cpu().double()
+    for b in range(B):
+        yo, go = O.decoder_jacobian(od, lat[b], pts[b])
+        assert torch.isfinite(y[b]).all() and torch.isfinite(J[b]).all()
+        assert float(yo.abs().max()) < 0.05 and float((yo < 0).float().mean()) > 0.05      # queries straddle the surface
+        assert float((y[b] - yo).abs().max()) < tol_y
+        assert float((J[b, :, :L] - go[:, :L]).abs().max() / go[:, :L].abs().max()) < tol_j
+        assert float((J[b, :, L:L + 3] - go[:, L:]).abs().max() / go[:, L:].abs().max()) < tol_j
