@@ -92,14 +92,13 @@ __device__ __forceinline__ void step_p(f32x16 (&acc)[NRB][NQB], const ASetP& a, 
 
 template <bool U0, bool U1>
 __device__ __forceinline__ void gemm_loop_p(f32x16 (&acc)[NRB][NQB], const f16x8* __restrict__ wp0,
-                                            const f16x8* __restrict__ wp1, int n_k16, const f16x8* xp, int lane_) {
+                                            const f16x8* __restrict__ wp1, int n_k16, const f16x8* xp) {
   // The lane id is re-derived HERE (volatile asm: not CSE'd with the kernel's copy) so that the LDS read pointer of the
   // loop is computed in its preheader instead of being reloaded from a spill slot: a scratch reload still in flight
   // at loop entry makes hipcc's wait-count pass put s_waitcnt vmcnt(0) in front of the first ds_read of EVERY
   // iteration, which drains the weight prefetch ring (effective prefetch distance: one K-step).
   int lane;
   asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
-  (void)lane_;
   const int xo = (lane >> 5) * TQP + (lane & 31);
   const int last = n_k16 - 1;
   ASetP a0 = {}, a1 = {}, a2 = {};
@@ -144,6 +143,11 @@ __device__ __forceinline__ void load_group_p(const f16x8* xp, int grp, int q, fl
 
 // ReLU masks: 128 bits per lane and layer (2 row blocks x 4 query blocks x 16 accumulator registers)
 struct Mask { uint32_t w[4]; };   // w[2 * r + (nb >> 1)], bit (nb & 1) * 16 + reg
+
+// Optional shader-clock stamps of workgroup 0 (hm_debug_set_k1p_trace, scripts/gpu_trace_k1p.py).  Wave 0, per stage s:
+// [5 s + 0] stage entered (after the X barrier), +1 K loop starts, +2 K loop done, +3 barrier passed, +4 epilogue done;
+// [80 + 2 w], [81 + 2 w]: K loop start / end of every wave w in stage 5.
+__device__ long long* g_k1p_trace = nullptr;
 
 #define HM_MASK_CASES(OP) \
   case 0: OP(mk0); break; case 1: OP(mk1); break; case 2: OP(mk2); break; case 3: OP(mk3); break; \
@@ -208,6 +212,9 @@ __global__ __launch_bounds__(512, 2) void k_decoder_p(const DecodeArgsP a) {
     for (int r = 0; r < NRB; ++r) u[r] = (w + 8 * r >= sd.mb_lo) && (w + 8 * r < sd.mb_hi);
     const float us = sh.unscale;
     __syncthreads();
+    const bool trc = g_k1p_trace != nullptr && blockIdx.x == 0 && tid == 0;
+    const bool trw = g_k1p_trace != nullptr && blockIdx.x == 0 && lane == 0 && s == 5;
+    if (trc) g_k1p_trace[5 * s + 0] = clock64();
 
     if (MODE == 1 && (epi == EPI_BWD4 || epi == EPI_BWD0)) {
       // xyz columns of lin4 / lin0 (512 x 4) through LDS scratch, then this wave's 64 rows against both query halves
@@ -255,15 +262,20 @@ __global__ __launch_bounds__(512, 2) void k_decoder_p(const DecodeArgsP a) {
       }
     }
 
+    if (trc) g_k1p_trace[5 * s + 1] = clock64();
+    if (trw) g_k1p_trace[80 + 2 * w] = clock64();
     {
       const f16x8* wp = reinterpret_cast<const f16x8*>(sh.wp);
       const f16x8* wp0 = wp + (size_t)(w - sd.mb_lo) * sh.mb_stride + lane;
       const f16x8* wp1 = wp + (size_t)(w + 8 - sd.mb_lo) * sh.mb_stride + lane;
-      if (u[0] && u[1]) gemm_loop_p<true, true>(acc, wp0, wp1, sh.n_k16, xp, lane);
-      else if (u[0]) gemm_loop_p<true, false>(acc, wp0, wp1, sh.n_k16, xp, lane);
-      else if (u[1]) gemm_loop_p<false, true>(acc, wp0, wp1, sh.n_k16, xp, lane);
+      if (u[0] && u[1]) gemm_loop_p<true, true>(acc, wp0, wp1, sh.n_k16, xp);
+      else if (u[0]) gemm_loop_p<true, false>(acc, wp0, wp1, sh.n_k16, xp);
+      else if (u[1]) gemm_loop_p<false, true>(acc, wp0, wp1, sh.n_k16, xp);
     }
+    if (trc) g_k1p_trace[5 * s + 2] = clock64();
+    if (trw) g_k1p_trace[81 + 2 * w] = clock64();
     __syncthreads();
+    if (trc) g_k1p_trace[5 * s + 3] = clock64();
 
     if (MODE == 0 || epi <= EPI_FWD7) {
       const float* bias = bl + s * HID;
@@ -420,6 +432,7 @@ __global__ __launch_bounds__(512, 2) void k_decoder_p(const DecodeArgsP a) {
         }
       }
     }
+    if (trc) g_k1p_trace[5 * s + 4] = clock64();
   }
 
   if (MODE == 0) return;
@@ -453,6 +466,10 @@ __global__ __launch_bounds__(512, 2) void k_decoder_p(const DecodeArgsP a) {
 }
 
 }  // namespace
+
+extern "C" void hm_debug_set_k1p_trace(long long* d_buf) {
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_k1p_trace), &d_buf, sizeof(d_buf));
+}
 
 namespace hm {
 

@@ -183,6 +183,7 @@ int hm_render_residuals(hm_workspace_t ws, const hm_opt_cfg* cfg, const hm_batch
  * the f16x3 decoder kernel / of the solve kernel writes shader-clock stamps per stage into it (scripts/gpu_trace_*.py). */
 void hm_debug_set_trace(long long* d_buf);      /* [NSTAGE * 4 + 1] or NULL */
 void hm_debug_set_k5_trace(long long* d_buf);   /* [32] or NULL */
+void hm_debug_set_k1p_trace(long long* d_buf);  /* [5 * 16] or NULL: per-stage stamps of the plain-fp16 decoder kernel */
 
 /* ---- unit hooks (tests): the device functions of the solve kernel / normal-equation kernel on caller-supplied values.
  * hm_debug_exp_map replaces exp_sim3 (sim3 != 0; wild_completion/utils.py:279-324) / exp_se3 (:220-254) for n tangents
