@@ -206,6 +206,27 @@ int hm_extract_surface(int B, const float* d_sdf, int n, float level, float cube
  * d_a4 [na][4], d_b4 [nb][4]: xyz + one ignored pad float per point; centre both clouds first (fp32 differences). */
 int hm_nn_distance(const float* d_a4, int na, const float* d_b4, int nb, float* d_dist, void* stream);
 
+/* ---- caller-side data preparation on the device: the image scans of `get_render_data`
+ * (wild_completion/utils.py:39-109).  d_id_imgs [F][H][W] int32 instance-id images, d_depth
+ * [F][H][W] float32 depth images of one sequence, resident on the device.
+ *
+ * hm_prep_stats: for every instance slot s = d_lut[id] (d_lut [lut_size], -1 = not wanted) and frame f,
+ *   d_stats[s][f][5] = {count, v_min, v_max, u_min, u_max} of the pixels with that id and depth > 0 (:51-63).  The
+ *   caller initialises d_stats to {0, INT_MAX, -1, INT_MAX, -1}.
+ * hm_prep_scan: one pass over the padded bounding box of every (instance, frame) pair, raster order (:68-73).
+ *   d_pairs [P][8] = {instance id, frame, min_v, max_v, min_u, max_u, n_sel_bg, n_sel_fg}.
+ *   gather == 0: d_counts[p] = {#background candidates (id != instance, :74), #foreground candidates (id == instance
+ *   and depth > 0, :85)}.  gather == 1: the candidate of raster rank r of kind c (0 bg, 1 fg) is kept when r is in
+ *   d_sel[p][c][0..n_sel) (sorted ascending; the host's np.random.choice draw, :79/:90) and written to output row
+ *   d_perm[p][c][i] (the position of r in the draw), or, when n_sel < 0 (no sub-sampling: at most `cap` candidates),
+ *   to row r: d_pix [P][2][cap][2] = (u, v), d_depth_out [P][2][cap], d_rays [P][2][cap][3] = K^-1 [u, v, 1] rounded
+ *   from fp64 like get_rays (:23-37); d_invK [9] fp64 row-major. */
+int hm_prep_stats(const int* d_id_imgs, const float* d_depth, int F, int H, int W, const int* d_lut, int lut_size,
+                  int B, int* d_stats, void* stream);
+int hm_prep_scan(const int* d_id_imgs, const float* d_depth, int H, int W, const int* d_pairs, int P, int gather,
+                 int* d_counts, const int* d_sel, const int* d_perm, int cap, const double* d_invK, int* d_pix,
+                 float* d_depth_out, float* d_rays, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

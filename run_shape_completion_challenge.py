@@ -71,7 +71,9 @@ def main(config):
             id_imgs[fr["fname"]] = (fr["mask"] > 0).astype(np.int32)        # 0 or 1, cur_submap_id = 1 (:86,166)
             depth_imgs[fr["fname"]] = fr["depth"]
             poses[fr["fname"]] = fr["pose"]
-        render_data = DP.get_render_data(1, id_imgs, depth_imgs, poses, img_size, invK, cfg, max_bbx_size=1000)
+        # the image scans run on the GPU; the random draws keep their place in the reference's RNG stream (:145, then here)
+        render_data = DP.get_render_data_device([1], DP.DeviceFrames(id_imgs, depth_imgs), poses, img_size, invK, cfg,
+                                                max_bbx_size=1000)[0]
         inst = Instance(init_latent.clone(), torch.eye(4, dtype=dtype), torch.tensor(pts, dtype=dtype), render_data,
                         object_radius_max_m, True)
         jobs.append((fid, item.get("groundtruth_pcd"), inst))

@@ -71,17 +71,26 @@ def main(config):
     mesh_extractor = MeshExtractor(decoder, code_len=code_len, voxels_dim=voxels_dim, cube_radius=object_radius_max_m)
     opt = Optimizer(cfg, decoder, mesh_extractor, None)
 
-    jobs, bg_points = [], np.zeros((0, 3))
-    for submap_name in sorted(os.listdir(submap_folder)):                # instance loop, :133
+    # instance loop of the reference (:133), split in two so that the image scans of get_render_data run on the GPU for
+    # all instances at once; the np.random.choice draws inside keep the reference's order (submap by submap)
+    entries, bg_at = [], {}
+    for submap_name in sorted(os.listdir(submap_folder)):
         submap_cat = (submap_name.split("_")[1]).split(".")[0]
         submap_id = int(submap_name.split("_")[0])
         if submap_id > 1 and submap_id < cfg["begin_submap"]:
             continue
         cur_mesh = read_ply(os.path.join(submap_folder, submap_name))
-        if submap_cat == "Background":                                   # :148-151
-            bg_points = DP.voxel_down_sample(cur_mesh.sample_points_uniformly(500000, seed=42), 0.005)
+        if submap_cat == "Background":                                   # :148-151 -- seen by the submaps AFTER it
+            bg_at[len(entries)] = DP.voxel_down_sample(cur_mesh.sample_points_uniformly(500000, seed=42), 0.005)
             continue
-        render_data = DP.get_render_data(submap_id, frames["id"], frames["depth"], frames["pose"], img_size, invK, cfg)
+        entries.append((submap_name, submap_id, cur_mesh))
+    dev_frames = DP.DeviceFrames(frames["id"], frames["depth"])
+    render_all = DP.get_render_data_device([e[1] for e in entries], dev_frames, frames["pose"], img_size, invK, cfg)
+
+    jobs, bg_points = [], np.zeros((0, 3))
+    for k, ((submap_name, submap_id, cur_mesh), render_data) in enumerate(zip(entries, render_all)):
+        if k in bg_at:
+            bg_points = bg_at[k]
         if render_data["count"] == 0:
             print("Submap %d: no valid match, skip" % submap_id)
             continue
