@@ -173,6 +173,132 @@ __global__ __launch_bounds__(NTP) void k_prep_scan(const int* __restrict__ id_im
   }
 }
 
+
+// ---- clean_pcd (utils.py:407-417): DBSCAN of one instance's surface samples, one workgroup per instance.
+// Points (fp64, as the KD-tree of the reference's / scikit-learn's DBSCAN sees them) and component ids live in LDS; every
+// pass is a brute-force n x n sweep (n <= DB_MAXN: 26 M distance tests for 5,120 points, microseconds on one CU).
+//   1. neighbour counts (self included, d <= eps): core points have >= min_pts;
+//   2. connected components of the core points under eps-adjacency by min-label propagation with pointer jumping
+//      (label = smallest core index of the component; the fixed point is unique, so the result is deterministic);
+//   3. a non-core point with core neighbours joins the adjacent component with the SMALLEST first core index -- the
+//      cluster scikit-learn's index-ordered expansion reaches it from first; without core neighbours it is noise (-1).
+// Output comp[b][i] = smallest core index of i's cluster, or -1: the host turns ranks of these into DBSCAN labels.
+constexpr int DB_NT = 1024;
+constexpr int DB_MAXN = 5120;
+
+__global__ __launch_bounds__(DB_NT) void k_dbscan(const double* __restrict__ pts, const int* __restrict__ n_pts,
+                                                  int n_stride, double eps, const int* __restrict__ min_pts,
+                                                  int* __restrict__ comp_out) {
+  extern __shared__ double dsm[];
+  double* px = dsm;                       // [3][DB_MAXN]
+  int* comp = reinterpret_cast<int*>(dsm + 3 * DB_MAXN);
+  __shared__ int changed;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int n = n_pts[b];
+  const int mp = min_pts[b];
+  const double e2 = eps * eps;
+  const double* pb = pts + (size_t)b * n_stride * 3;
+  for (int i = tid; i < n; i += DB_NT) {
+    px[i] = pb[3 * i];
+    px[DB_MAXN + i] = pb[3 * i + 1];
+    px[2 * DB_MAXN + i] = pb[3 * i + 2];
+  }
+  __syncthreads();
+  constexpr int PER = DB_MAXN / DB_NT;
+  for (int r = 0; r < PER; ++r) {
+    const int i = tid + r * DB_NT;
+    if (i < n) {
+      const double x = px[i], y = px[DB_MAXN + i], z = px[2 * DB_MAXN + i];
+      int cnt = 0;
+      for (int j = 0; j < n; ++j) {
+        const double dx = px[j] - x, dy = px[DB_MAXN + j] - y, dz = px[2 * DB_MAXN + j] - z;
+        cnt += (dx * dx + dy * dy + dz * dz <= e2) ? 1 : 0;
+      }
+      comp[i] = cnt >= mp ? i : INT_MAX;
+    }
+  }
+  __syncthreads();
+  for (int it = 0; it < 4 * DB_MAXN; ++it) {
+    if (tid == 0) changed = 0;
+    __syncthreads();
+    for (int r = 0; r < PER; ++r) {
+      const int i = tid + r * DB_NT;
+      if (i < n && comp[i] != INT_MAX) {
+        const double x = px[i], y = px[DB_MAXN + i], z = px[2 * DB_MAXN + i];
+        int m = comp[i];
+        for (int j = 0; j < n; ++j) {
+          const int cj = comp[j];
+          if (cj < m) {
+            const double dx = px[j] - x, dy = px[DB_MAXN + j] - y, dz = px[2 * DB_MAXN + j] - z;
+            if (dx * dx + dy * dy + dz * dz <= e2) m = cj;
+          }
+        }
+        const int mm = comp[m];               // pointer jump: the label of my label (labels are core indices)
+        if (mm < m) m = mm;
+        if (m < comp[i]) { comp[i] = m; changed = 1; }
+      }
+    }
+    __syncthreads();
+    if (!changed) break;
+    __syncthreads();
+  }
+  int* out = comp_out + (size_t)b * n_stride;
+  for (int r = 0; r < PER; ++r) {
+    const int i = tid + r * DB_NT;
+    if (i < n) {
+      int m = comp[i];
+      if (m == INT_MAX) {                      // border or noise
+        const double x = px[i], y = px[DB_MAXN + i], z = px[2 * DB_MAXN + i];
+        for (int j = 0; j < n; ++j) {
+          const int cj = comp[j];
+          if (cj < m) {
+            const double dx = px[j] - x, dy = px[DB_MAXN + j] - y, dz = px[2 * DB_MAXN + j] - z;
+            if (dx * dx + dy * dy + dz * dz <= e2) m = cj;
+          }
+        }
+      }
+      out[i] = m == INT_MAX ? -1 : m;
+    }
+  }
+}
+
+// ---- get_pose_init's crop of the background cloud (utils.py:442-447): indices, in input order, of the points inside an
+// axis-aligned box (closed bounds, fp64 compares like numpy); one workgroup per box.  GATHER false: counts only.
+template <bool GATHER>
+__global__ __launch_bounds__(NTP) void k_box_select(const double* __restrict__ pts, int n, const double* __restrict__ boxes,
+                                                    int* __restrict__ counts, const long long* __restrict__ offsets,
+                                                    int* __restrict__ idx_out) {
+  __shared__ int s_tot[NTP / 64];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  double lo[3], hi[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) { lo[c] = boxes[b * 6 + c]; hi[c] = boxes[b * 6 + 3 + c]; }
+  int run = 0;
+  int* out = GATHER ? idx_out + offsets[b] : nullptr;
+  for (int base = 0; base < n; base += NTP) {
+    const int i = base + tid;
+    bool in = false;
+    if (i < n) {
+      const double x = pts[3 * (size_t)i], y = pts[3 * (size_t)i + 1], z = pts[3 * (size_t)i + 2];
+      in = x >= lo[0] && x <= hi[0] && y >= lo[1] && y <= hi[1] && z >= lo[2] && z <= hi[2];
+    }
+    const unsigned long long m = __ballot(in);
+    const int pre = __popcll(m & ((1ull << lane) - 1ull));
+    if (lane == 0) s_tot[wv] = __popcll(m);
+    __syncthreads();
+    int off = 0, tot = 0;
+#pragma unroll
+    for (int w2 = 0; w2 < NTP / 64; ++w2) {
+      if (w2 < wv) off += s_tot[w2];
+      tot += s_tot[w2];
+    }
+    if (GATHER && in) out[run + off + pre] = i;
+    run += tot;
+    __syncthreads();
+  }
+  if (!GATHER && tid == 0) counts[b] = run;
+}
+
 }  // namespace
 
 extern "C" int hm_prep_stats(const int* d_id_imgs, const float* d_depth, int F, int H, int W, const int* d_lut,
@@ -202,6 +328,36 @@ extern "C" int hm_prep_scan(const int* d_id_imgs, const float* d_depth, int H, i
     hipLaunchKernelGGL((k_prep_scan<false>), dim3(P), dim3(NTP), 8 * sizeof(int), st, d_id_imgs, d_depth, H, W, d_pairs,
                        d_counts, d_sel, d_perm, cap, d_invK, d_pix, d_depth_out, d_rays);
   }
+  HM_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int hm_prep_dbscan(const double* d_pts, const int* d_n_pts, int n_stride, int B, double eps, const int* d_min_pts,
+                              int* d_comp, void* stream) {
+  if (B < 0 || n_stride <= 0 || n_stride > DB_MAXN || !(eps > 0.0)) {
+    hm_set_error("hm_prep_dbscan: bad argument (at most %d points per instance)", DB_MAXN);
+    return -1;
+  }
+  if (B == 0) return 0;
+  static bool attr_set = false;
+  const size_t sm = (size_t)3 * DB_MAXN * sizeof(double) + (size_t)DB_MAXN * sizeof(int);
+  if (!attr_set) {
+    HM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_dbscan), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(k_dbscan, dim3(B), dim3(DB_NT), sm, static_cast<hipStream_t>(stream), d_pts, d_n_pts, n_stride, eps,
+                     d_min_pts, d_comp);
+  HM_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int hm_prep_box_select(const double* d_pts, int n, const double* d_boxes, int B, int gather, int* d_counts,
+                                  const long long* d_offsets, int* d_idx, void* stream) {
+  if (n < 0 || B < 0) { hm_set_error("hm_prep_box_select: bad argument"); return -1; }
+  if (B == 0) return 0;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (gather) hipLaunchKernelGGL((k_box_select<true>), dim3(B), dim3(NTP), 0, st, d_pts, n, d_boxes, d_counts, d_offsets, d_idx);
+  else hipLaunchKernelGGL((k_box_select<false>), dim3(B), dim3(NTP), 0, st, d_pts, n, d_boxes, d_counts, d_offsets, d_idx);
   HM_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -196,14 +196,67 @@ def get_render_data_device(submap_ids, frames: DeviceFrames, cam_poses, img_size
     return out
 
 
+def _mode_cluster(points, labels):
+    mode_label = Counter(labels.tolist()).most_common(1)[0][0]
+    return points[labels == mode_label]
+
+
 def clean_pcd(points: np.ndarray, cluster_dist_thre=0.01, outlier_point_ratio=0.02) -> np.ndarray:
     """`utils.py:407-417`: keep the most populated DBSCAN cluster."""
     from sklearn.cluster import DBSCAN
     n = points.shape[0]
     min_pts = max(1, int(n * outlier_point_ratio))
     labels = DBSCAN(eps=cluster_dist_thre, min_samples=min_pts).fit(points).labels_
-    mode_label = Counter(labels.tolist()).most_common(1)[0][0]
-    return points[labels == mode_label]
+    return _mode_cluster(points, labels)
+
+
+DBSCAN_MAX_POINTS = 5120
+
+
+def dbscan_labels_device(clouds, eps, min_pts):
+    """DBSCAN labels of several point clouds at once on the GPU (`hm_prep_dbscan`, one workgroup per cloud, at most
+    DBSCAN_MAX_POINTS points each): same partition and same label numbering as scikit-learn's DBSCAN (clusters numbered
+    by their first core point, border points to the earliest-numbered adjacent cluster, noise -1)."""
+    import ctypes
+    from . import _lib
+    lib = _lib.lib()
+    vp, ci = ctypes.c_void_p, ctypes.c_int
+    lib.hm_prep_dbscan.restype = ci
+    lib.hm_prep_dbscan.argtypes = [vp, vp, ci, ci, ctypes.c_double, vp, vp, vp]
+    B = len(clouds)
+    if B == 0:
+        return []
+    ns = [int(c.shape[0]) for c in clouds]
+    n_stride = max(max(ns), 1)
+    if n_stride > DBSCAN_MAX_POINTS:
+        raise ValueError(f"dbscan_labels_device: at most {DBSCAN_MAX_POINTS} points per cloud (got {n_stride})")
+    buf = np.zeros((B, n_stride, 3), np.float64)
+    for b, c in enumerate(clouds):
+        buf[b, :ns[b]] = c
+    dev = torch.device("cuda")
+    d_pts = torch.from_numpy(buf).to(dev)
+    d_n = torch.tensor(ns, dtype=torch.int32, device=dev)
+    d_mp = torch.tensor([int(m) for m in min_pts], dtype=torch.int32, device=dev)
+    d_comp = torch.full((B, n_stride), -1, dtype=torch.int32, device=dev)
+    _lib.check(lib.hm_prep_dbscan(d_pts.data_ptr(), d_n.data_ptr(), n_stride, B, float(eps), d_mp.data_ptr(), d_comp.data_ptr(),
+                                  ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "hm_prep_dbscan")
+    comp = d_comp.cpu().numpy()
+    out = []
+    for b in range(B):
+        c = comp[b, :ns[b]]
+        roots = np.unique(c[c >= 0])                      # ascending first-core index = scikit-learn's cluster order
+        lab = np.full(ns[b], -1, np.int64)
+        if len(roots):
+            lab[c >= 0] = np.searchsorted(roots, c[c >= 0])
+        out.append(lab)
+    return out
+
+
+def clean_pcd_device(clouds, cluster_dist_thre=0.01, outlier_point_ratio=0.02):
+    """`clean_pcd` (`utils.py:407-417`) for a list of clouds, DBSCAN on the GPU."""
+    min_pts = [max(1, int(c.shape[0] * outlier_point_ratio)) for c in clouds]
+    labels = dbscan_labels_device(clouds, cluster_dist_thre, min_pts)
+    return [_mode_cluster(c, l) for c, l in zip(clouds, labels)]
 
 
 def clean_mesh(mesh, sample_point_count=5000, cluster_dist_thre=0.01, outlier_point_ratio=0.02, seed=0) -> np.ndarray:
@@ -212,15 +265,14 @@ def clean_mesh(mesh, sample_point_count=5000, cluster_dist_thre=0.01, outlier_po
     return clean_pcd(pts, cluster_dist_thre, outlier_point_ratio)
 
 
-def get_pose_init(cur_points: np.ndarray, bg_points: np.ndarray, bbx_pad=0.01, min_bbx_size=0.03, max_bbx_size=0.16,
-                  min_nearby_bg_pts=10, max_init_rot_deg=45):
-    """`utils.py:420-459`: bbox centre (shifted along y), y-rotation from the peduncle support, bbox size, validity."""
+def pose_init_box(cur_points: np.ndarray, bbx_pad=0.01, min_bbx_size=0.03, max_bbx_size=0.16):
+    """First half of `get_pose_init` (`utils.py:420-441`): bbox centre (shifted along y), bbox size, validity and the
+    box [bmin, bmax] in which background points vote for the initial rotation."""
     lo, hi = cur_points.min(axis=0), cur_points.max(axis=0)
     center, extent = 0.5 * (lo + hi), hi - lo
     bbx_size = float(extent.max() + bbx_pad)
     valid = not (bbx_size > max_bbx_size or bbx_size < min_bbx_size)
-    rot_y = 0.0
-    max_rot = max_init_rot_deg / 180.0 * math.pi
+    bmin = bmax = None
     if valid:
         center = center.copy()
         center[1] += (bbx_size - extent[1]) * 0.5
@@ -228,13 +280,71 @@ def get_pose_init(cur_points: np.ndarray, bg_points: np.ndarray, bbx_pad=0.01, m
             center[1] += 0.01
         bmin = np.array([center[0] - 0.6 * bbx_size, center[1] - 0.8 * bbx_size, center[2] + 0.2 * bbx_size])
         bmax = np.array([center[0] + 0.6 * bbx_size, center[1] + 1.0 * bbx_size, center[2] + 1.2 * bbx_size])
-        if bg_points is not None and len(bg_points):
-            crop = bg_points[np.all((bg_points >= bmin) & (bg_points <= bmax), axis=1)]
-            if len(crop) > min_nearby_bg_pts:
-                rot_vec = np.mean(crop - center, axis=0)
-                rot_y = 0.5 * math.pi - np.arctan2(rot_vec[2], rot_vec[0])
-                rot_y = max(min(rot_y, max_rot), -max_rot)
+    return center, bbx_size, valid, bmin, bmax
+
+
+def pose_init_rotation(center, crop, min_nearby_bg_pts=10, max_init_rot_deg=45):
+    """Second half (`utils.py:442-457`): y-rotation from the mean offset of the cropped background points."""
+    rot_y = 0.0
+    max_rot = max_init_rot_deg / 180.0 * math.pi
+    if crop is not None and len(crop) > min_nearby_bg_pts:
+        rot_vec = np.mean(crop - center, axis=0)
+        rot_y = 0.5 * math.pi - np.arctan2(rot_vec[2], rot_vec[0])
+        rot_y = max(min(rot_y, max_rot), -max_rot)
+    return float(rot_y)
+
+
+def get_pose_init(cur_points: np.ndarray, bg_points: np.ndarray, bbx_pad=0.01, min_bbx_size=0.03, max_bbx_size=0.16,
+                  min_nearby_bg_pts=10, max_init_rot_deg=45):
+    """`utils.py:420-459`: bbox centre (shifted along y), y-rotation from the peduncle support, bbox size, validity."""
+    center, bbx_size, valid, bmin, bmax = pose_init_box(cur_points, bbx_pad, min_bbx_size, max_bbx_size)
+    rot_y = 0.0
+    if valid and bg_points is not None and len(bg_points):
+        crop = bg_points[np.all((bg_points >= bmin) & (bg_points <= bmax), axis=1)]
+        rot_y = pose_init_rotation(center, crop, min_nearby_bg_pts, max_init_rot_deg)
     return center, float(rot_y), bbx_size, valid
+
+
+class DeviceCloud:
+    """A point cloud (fp64) resident on the GPU, for repeated box crops (`crop_boxes`)."""
+
+    def __init__(self, points: np.ndarray, device="cuda"):
+        self.host = np.ascontiguousarray(np.asarray(points, dtype=np.float64).reshape(-1, 3))
+        self.dev = torch.from_numpy(self.host).to(device)
+
+    def __len__(self):
+        return self.host.shape[0]
+
+    def crop_boxes(self, bmins, bmaxs):
+        """For every closed box [bmin, bmax]: the points inside, in input order -- what
+        `pts[np.all((pts >= bmin) & (pts <= bmax), axis=1)]` returns (`hm_prep_box_select`: count pass, gather pass)."""
+        import ctypes
+        from . import _lib
+        lib = _lib.lib()
+        vp, ci = ctypes.c_void_p, ctypes.c_int
+        lib.hm_prep_box_select.restype = ci
+        lib.hm_prep_box_select.argtypes = [vp, ci, vp, ci, ci, vp, vp, vp, vp]
+        B = len(bmins)
+        if B == 0:
+            return []
+        if len(self) == 0:
+            return [self.host[:0] for _ in range(B)]
+        dev = self.dev.device
+        st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        boxes = torch.from_numpy(np.concatenate([np.asarray(bmins, np.float64).reshape(B, 3),
+                                                 np.asarray(bmaxs, np.float64).reshape(B, 3)], axis=1)).to(dev)
+        d_counts = torch.zeros(B, dtype=torch.int32, device=dev)
+        nul = ctypes.c_void_p(0)
+        _lib.check(lib.hm_prep_box_select(self.dev.data_ptr(), len(self), boxes.data_ptr(), B, 0, d_counts.data_ptr(), nul,
+                                          nul, st), "hm_prep_box_select(count)")
+        counts = d_counts.cpu().numpy().astype(np.int64)
+        offs = np.concatenate([[0], np.cumsum(counts)])
+        d_offs = torch.from_numpy(offs[:-1].copy()).to(dev)
+        d_idx = torch.zeros(max(int(offs[-1]), 1), dtype=torch.int32, device=dev)
+        _lib.check(lib.hm_prep_box_select(self.dev.data_ptr(), len(self), boxes.data_ptr(), B, 1, d_counts.data_ptr(),
+                                          d_offs.data_ptr(), d_idx.data_ptr(), st), "hm_prep_box_select(gather)")
+        idx = d_idx.cpu().numpy()
+        return [self.host[idx[offs[b]:offs[b + 1]]] for b in range(B)]
 
 
 def init_T_wo(center, rot_y_rad, bbx_size, cfg_opt, object_radius_max_m):

@@ -227,6 +227,20 @@ int hm_prep_scan(const int* d_id_imgs, const float* d_depth, int H, int W, const
                  int* d_counts, const int* d_sel, const int* d_perm, int cap, const double* d_invK, int* d_pix,
                  float* d_depth_out, float* d_rays, void* stream);
 
+
+/* hm_prep_dbscan: `clean_pcd` (wild_completion/utils.py:407-417) -- DBSCAN of each instance's surface samples, one
+ *   workgroup per instance.  d_pts [B][n_stride][3] fp64, d_n_pts [B], n_stride <= 5120, eps = cluster_dist_thre,
+ *   d_min_pts [B] = max(1, int(n * outlier_point_ratio)).  d_comp [B][n_stride]: the smallest core-point index of the
+ *   point's cluster, -1 for noise; a border point joins the adjacent cluster with the smallest first core index (what an
+ *   index-ordered DBSCAN expansion does).  Ranking the distinct values gives the DBSCAN labels.
+ * hm_prep_box_select: the background crop of `get_pose_init` (:442-447): indices, in input order, of the points of
+ *   d_pts [n][3] fp64 inside each closed box d_boxes [B][6] = {min xyz, max xyz}.  gather == 0: d_counts [B];
+ *   gather == 1: indices of box b written from d_idx + d_offsets[b]. */
+int hm_prep_dbscan(const double* d_pts, const int* d_n_pts, int n_stride, int B, double eps, const int* d_min_pts,
+                   int* d_comp, void* stream);
+int hm_prep_box_select(const double* d_pts, int n, const double* d_boxes, int B, int gather, int* d_counts,
+                       const long long* d_offsets, int* d_idx, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -64,7 +64,7 @@ def main(config):
         n_down = cfg["opt"]["recon"]["n_pts"]
         if pts.shape[0] > n_down:                                           # random_down_sample, :145
             pts = pts[np.random.choice(pts.shape[0], n_down, replace=False)]
-        pts = DP.clean_pcd(pts, cfg["opt"]["recon"]["cluster_dist_m"])
+        pts = DP.clean_pcd_device([pts], cfg["opt"]["recon"]["cluster_dist_m"])[0]      # DBSCAN on the GPU
         id_imgs, depth_imgs, poses = {}, {}, {}
         for k in frame_ids[sel]:
             fr = frames[k]

@@ -87,21 +87,42 @@ def main(config):
     dev_frames = DP.DeviceFrames(frames["id"], frames["depth"])
     render_all = DP.get_render_data_device([e[1] for e in entries], dev_frames, frames["pose"], img_size, invK, cfg)
 
-    jobs, bg_points = [], np.zeros((0, 3))
-    for k, ((submap_name, submap_id, cur_mesh), render_data) in enumerate(zip(entries, render_all)):
-        if k in bg_at:
-            bg_points = bg_at[k]
-        if render_data["count"] == 0:
-            print("Submap %d: no valid match, skip" % submap_id)
-            continue
-        pts = DP.clean_mesh(cur_mesh, cfg["opt"]["recon"]["n_pts"], cfg["opt"]["recon"]["cluster_dist_m"], seed=42)
-        center, rot_y, bbx_size, valid = DP.get_pose_init(pts, bg_points)
+    # clean_pcd (DBSCAN) of all matched submaps in one launch, the background crops of get_pose_init per background cloud
+    matched = [k for k, rd in enumerate(render_all) if rd["count"] > 0]
+    for k, rd in enumerate(render_all):
+        if rd["count"] == 0:
+            print("Submap %d: no valid match, skip" % entries[k][1])
+    rc = cfg["opt"]["recon"]
+    samples = [entries[k][2].sample_points_uniformly(rc["n_pts"], seed=42) for k in matched]     # clean_mesh, utils.py:389-405
+    cleaned = dict(zip(matched, DP.clean_pcd_device(samples, rc["cluster_dist_m"]))) if matched else {}
+    boxes = {k: DP.pose_init_box(cleaned[k]) for k in matched}
+    crops, bg_cloud, pending = {}, None, []
+
+    def flush():
+        if pending and bg_cloud is not None and len(bg_cloud):
+            for k, c in zip(pending, bg_cloud.crop_boxes([boxes[k][3] for k in pending], [boxes[k][4] for k in pending])):
+                crops[k] = c
+        pending.clear()
+    for k in range(len(entries) + 1):
+        if k in bg_at:                                                   # a Background submap precedes entry k
+            flush()
+            bg_cloud = DP.DeviceCloud(bg_at[k])
+        if k in boxes and boxes[k][2]:
+            pending.append(k)
+    flush()
+
+    jobs = []
+    for k in matched:
+        submap_name, submap_id, _ = entries[k]
+        pts = cleaned[k]
+        center, bbx_size, valid, _, _ = boxes[k]
         if not valid:
             print("Submap %d: invalid pose initialisation, skip" % submap_id)
             continue
+        rot_y = DP.pose_init_rotation(center, crops.get(k))
         T_wo = DP.init_T_wo(center, rot_y, bbx_size, cfg["opt"], object_radius_max_m)
         inst = Instance(init_latent.clone(), torch.tensor(inv(T_wo), dtype=dtype), torch.tensor(pts, dtype=dtype),
-                        render_data, object_radius_max_m, False)
+                        render_all[k], object_radius_max_m, False)
         jobs.append((submap_name, submap_id, pts, inst))
     print("Optimising %d fruit instances in one batch" % len(jobs))
     results = opt.optimize_batch([j[3] for j in jobs]) if jobs else []

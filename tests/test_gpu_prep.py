@@ -99,3 +99,65 @@ def test_device_render_prep_empty_inputs():
     out = get_render_data_device([3, 4], frames, {0: np.eye(4)}, (32, 32), np.eye(3), _cfg(10, 10, 2))
     assert [r["count"] for r in out] == [0, 0]
     assert get_render_data_device([], frames, {0: np.eye(4)}, (32, 32), np.eye(3), _cfg(10, 10, 2)) == []
+
+
+def _fruit_cloud(rs, n, n_out_cluster, n_noise):
+    d = rs.randn(6 * n, 3)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    d = d[d[:, 2] < -0.2][:n]
+    return np.concatenate([0.04 * d + [0.1, 0.2, 0.5], 0.004 * rs.randn(n_out_cluster, 3) + [0.17, 0.2, 0.5],
+                           rs.uniform(-0.1, 0.1, (n_noise, 3)) + [0.1, 0.2, 0.5]])
+
+
+def test_device_dbscan_equals_scikit_learn():
+    """`hm_prep_dbscan` against scikit-learn's DBSCAN (the stand-in for Open3D's cluster_dbscan in clean_pcd,
+    utils.py:407-417): identical label arrays -- same core points, same clusters in the same numbering, border points
+    assigned to the same cluster, same noise -- on fruit-like caps with satellite clusters and noise, on touching
+    blobs (border points adjacent to two clusters), on a cloud that is all noise and on one that is one cluster."""
+    from sklearn.cluster import DBSCAN
+    from hortimapping_amd.data_prep import clean_pcd, clean_pcd_device, dbscan_labels_device
+    rs = np.random.RandomState(5)
+    clouds = [_fruit_cloud(rs, 1800, 150, 50), _fruit_cloud(rs, 4600, 300, 100), _fruit_cloud(rs, 400, 0, 10)]
+    a = rs.randn(600, 3) * 0.006
+    clouds.append(np.concatenate([a, a + [0.024, 0, 0], a + [0.012, 0.021, 0]]))        # three touching blobs
+    clouds.append(rs.uniform(-1, 1, (700, 3)))                                           # all noise at eps = 1 cm
+    clouds.append(0.003 * rs.randn(900, 3))                                              # one cluster
+    clouds.append(rs.uniform(0, 0.05, (5120, 3)))                                        # the size limit
+    for eps, ratio in ((0.01, 0.02), (0.006, 0.01)):
+        mp = [max(1, int(len(c) * ratio)) for c in clouds]
+        got = dbscan_labels_device(clouds, eps, mp)
+        for c, m, g in zip(clouds, mp, got):
+            ref = DBSCAN(eps=eps, min_samples=m).fit(c).labels_
+            assert np.array_equal(g, ref), (len(c), eps, m, int((g != ref).sum()))
+    kept_dev = clean_pcd_device(clouds[:4], 0.01, 0.02)
+    for c, k in zip(clouds[:4], kept_dev):
+        assert np.array_equal(k, clean_pcd(c, 0.01, 0.02))
+    with pytest.raises(ValueError):
+        dbscan_labels_device([np.zeros((5121, 3))], 0.01, [1])
+
+
+def test_device_box_crop_equals_numpy():
+    """`hm_prep_box_select` (the background crop of get_pose_init, utils.py:442-447): same points in the same order as
+    the numpy boolean mask, closed bounds included, empty and all-inclusive boxes; get_pose_init assembled from the
+    two halves + the device crop equals the host function bit for bit."""
+    from hortimapping_amd.data_prep import DeviceCloud, get_pose_init, pose_init_box, pose_init_rotation
+    rs = np.random.RandomState(9)
+    bg = rs.uniform(-0.5, 0.5, (300001, 3))
+    bg[1000] = [0.1, 0.2, 0.3]
+    cloud = DeviceCloud(bg)
+    bmins = [np.array([0.1, 0.2, 0.3]), np.array([-0.2, -0.1, 0.0]), np.array([5.0, 5.0, 5.0]), np.array([-1.0, -1.0, -1.0])]
+    bmaxs = [np.array([0.2, 0.3, 0.4]), np.array([0.1, 0.25, 0.3]), np.array([6.0, 6.0, 6.0]), np.array([1.0, 1.0, 1.0])]
+    crops = cloud.crop_boxes(bmins, bmaxs)
+    for lo, hi, c in zip(bmins, bmaxs, crops):
+        ref = bg[np.all((bg >= lo) & (bg <= hi), axis=1)]
+        assert c.shape == ref.shape and np.array_equal(c, ref)
+    assert len(crops[2]) == 0 and len(crops[3]) == len(bg) and np.array_equal(crops[0][0], bg[1000])   # closed lower bound
+    fruits = [_fruit_cloud(rs, 1500, 0, 0) + rs.uniform(-0.3, 0.3, 3) for _ in range(6)]
+    boxes = [pose_init_box(f) for f in fruits]
+    assert all(b[2] for b in boxes)
+    crops = cloud.crop_boxes([b[3] for b in boxes], [b[4] for b in boxes])
+    for f, (center, size, valid, _, _), crop in zip(fruits, boxes, crops):
+        c_ref, rot_ref, size_ref, valid_ref = get_pose_init(f, bg)
+        assert np.array_equal(center, c_ref) and size == size_ref and valid == valid_ref
+        assert pose_init_rotation(center, crop) == rot_ref
+    assert DeviceCloud(np.zeros((0, 3))).crop_boxes(bmins[:1], bmaxs[:1])[0].shape == (0, 3)
