@@ -90,7 +90,7 @@ __device__ __forceinline__ void step_p(f32x16 (&acc)[NRB][NQB], const ASetP& a, 
   }
 }
 
-template <bool U0, bool U1>
+template <bool U0, bool U1, bool DRAIN>
 __device__ __forceinline__ void gemm_loop_p(f32x16 (&acc)[NRB][NQB], const f16x8* __restrict__ wp0,
                                             const f16x8* __restrict__ wp1, int n_k16, const f16x8* xp) {
   // The lane id is re-derived HERE (volatile asm: not CSE'd with the kernel's copy) so that the LDS read pointer of the
@@ -103,6 +103,10 @@ __device__ __forceinline__ void gemm_loop_p(f32x16 (&acc)[NRB][NQB], const f16x8
   const int last = n_k16 - 1;
   ASetP a0 = {}, a1 = {}, a2 = {};
   BSetP bq;
+  if (DRAIN) {   // forward-only kernel: something (a scalar load) is still pending here and poisons the loop head the
+    __builtin_amdgcn_s_waitcnt(0x0070);   // same way; draining once (vmcnt(0) lgkmcnt(0), gfx9 encoding) is free there.
+    HM_FENCE();                           // In the fwd+bwd kernel the drain would wait for epilogue stores: left out.
+  }
   auto lda = [&](ASetP& a, int k) {
     k = k < last ? k : last;
     if (U0) a.r[0] = wp0[k * 128];
@@ -144,10 +148,16 @@ __device__ __forceinline__ void load_group_p(const f16x8* xp, int grp, int q, fl
 // ReLU masks: 128 bits per lane and layer (2 row blocks x 4 query blocks x 16 accumulator registers)
 struct Mask { uint32_t w[4]; };   // w[2 * r + (nb >> 1)], bit (nb & 1) * 16 + reg
 
-// Optional shader-clock stamps of workgroup 0 (hm_debug_set_k1p_trace, scripts/gpu_trace_k1p.py).  Wave 0, per stage s:
-// [5 s + 0] stage entered (after the X barrier), +1 K loop starts, +2 K loop done, +3 barrier passed, +4 epilogue done;
-// [80 + 2 w], [81 + 2 w]: K loop start / end of every wave w in stage 5.
+// Shader-clock stamps of wave 0 of workgroup 0 (hm_debug_set_k1p_trace, scripts/gpu_trace_k1p.py), per stage s:
+// [5 s + 0] stage entered (after the X barrier), +1 K loop starts, +2 K loop done, +3 barrier passed, +4 epilogue done.
+// Compiled in only with -DHM_K1P_TRACE: even switched off at run time the stamps cost 3 % of the launch (more live
+// values, different spills), stamps of every wave 8 %.
 __device__ long long* g_k1p_trace = nullptr;
+#ifdef HM_K1P_TRACE
+#define HM_STAMP(SLOT) if (trc) g_k1p_trace[SLOT] = clock64()
+#else
+#define HM_STAMP(SLOT)
+#endif
 
 #define HM_MASK_CASES(OP) \
   case 0: OP(mk0); break; case 1: OP(mk1); break; case 2: OP(mk2); break; case 3: OP(mk3); break; \
@@ -212,9 +222,10 @@ __global__ __launch_bounds__(512, 2) void k_decoder_p(const DecodeArgsP a) {
     for (int r = 0; r < NRB; ++r) u[r] = (w + 8 * r >= sd.mb_lo) && (w + 8 * r < sd.mb_hi);
     const float us = sh.unscale;
     __syncthreads();
+#ifdef HM_K1P_TRACE
     const bool trc = g_k1p_trace != nullptr && blockIdx.x == 0 && tid == 0;
-    const bool trw = g_k1p_trace != nullptr && blockIdx.x == 0 && lane == 0 && s == 5;
-    if (trc) g_k1p_trace[5 * s + 0] = clock64();
+#endif
+    HM_STAMP(5 * s + 0);
 
     if (MODE == 1 && (epi == EPI_BWD4 || epi == EPI_BWD0)) {
       // xyz columns of lin4 / lin0 (512 x 4) through LDS scratch, then this wave's 64 rows against both query halves
@@ -262,20 +273,18 @@ __global__ __launch_bounds__(512, 2) void k_decoder_p(const DecodeArgsP a) {
       }
     }
 
-    if (trc) g_k1p_trace[5 * s + 1] = clock64();
-    if (trw) g_k1p_trace[80 + 2 * w] = clock64();
+    HM_STAMP(5 * s + 1);
     {
       const f16x8* wp = reinterpret_cast<const f16x8*>(sh.wp);
       const f16x8* wp0 = wp + (size_t)(w - sd.mb_lo) * sh.mb_stride + lane;
       const f16x8* wp1 = wp + (size_t)(w + 8 - sd.mb_lo) * sh.mb_stride + lane;
-      if (u[0] && u[1]) gemm_loop_p<true, true>(acc, wp0, wp1, sh.n_k16, xp);
-      else if (u[0]) gemm_loop_p<true, false>(acc, wp0, wp1, sh.n_k16, xp);
-      else if (u[1]) gemm_loop_p<false, true>(acc, wp0, wp1, sh.n_k16, xp);
+      if (u[0] && u[1]) gemm_loop_p<true, true, MODE == 0>(acc, wp0, wp1, sh.n_k16, xp);
+      else if (u[0]) gemm_loop_p<true, false, MODE == 0>(acc, wp0, wp1, sh.n_k16, xp);
+      else if (u[1]) gemm_loop_p<false, true, MODE == 0>(acc, wp0, wp1, sh.n_k16, xp);
     }
-    if (trc) g_k1p_trace[5 * s + 2] = clock64();
-    if (trw) g_k1p_trace[81 + 2 * w] = clock64();
+    HM_STAMP(5 * s + 2);
     __syncthreads();
-    if (trc) g_k1p_trace[5 * s + 3] = clock64();
+    HM_STAMP(5 * s + 3);
 
     if (MODE == 0 || epi <= EPI_FWD7) {
       const float* bias = bl + s * HID;
@@ -432,7 +441,7 @@ __global__ __launch_bounds__(512, 2) void k_decoder_p(const DecodeArgsP a) {
         }
       }
     }
-    if (trc) g_k1p_trace[5 * s + 4] = clock64();
+    HM_STAMP(5 * s + 4);
   }
 
   if (MODE == 0) return;

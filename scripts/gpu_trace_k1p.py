@@ -1,5 +1,7 @@
 """Per-stage shader-clock attribution of the plain-fp16 decoder kernel (wave 0 of workgroup 0): K loop, wait at the
-barrier, epilogue.  GPU box:  python scripts/gpu_trace_k1p.py"""
+barrier, epilogue.  Needs the library built with the stamps compiled in:
+    python -c "from hortimapping_amd import build; build.build(force=True, extra_flags=['-DHM_K1P_TRACE'])"
+GPU box:  python scripts/gpu_trace_k1p.py   (rebuild without the flag afterwards)"""
 import ctypes
 import sys
 
@@ -19,18 +21,14 @@ lib = _lib.lib()
 lib.hm_debug_set_k1p_trace.argtypes = [ctypes.c_void_p]
 for _ in range(3):
     ops.decode_batch(dec, lat, pts4, nq, mode=1, pose_dim=7)
-tr = torch.zeros(96, dtype=torch.int64, device="cuda")
+tr = torch.zeros(80, dtype=torch.int64, device="cuda")
 lib.hm_debug_set_k1p_trace(tr.data_ptr())
 ops.decode_batch(dec, lat, pts4, nq, mode=1, pose_dim=7)
 torch.cuda.synchronize()
 lib.hm_debug_set_k1p_trace(None)
-tw = tr.cpu().numpy()[80:].reshape(8, 2)
-t = tr.cpu().numpy()[:80].reshape(16, 5)
+t = tr.cpu().numpy().reshape(16, 5)
 print("stage   pre-loop     K loop   barrier   epilogue   | stage total (to next stage entry)")
 for s in range(16):
     nxt = t[s + 1, 0] if s < 15 else t[s, 4]
     print(f"{s:3d} {t[s,1]-t[s,0]:10d} {t[s,2]-t[s,1]:10d} {t[s,3]-t[s,2]:9d} {t[s,4]-t[s,3]:10d}   | {nxt - t[s,0]:8d}")
 print("tile total", t[15, 4] - t[0, 0])
-print("stage 5, K loop of every wave (start, end relative to wave 0's start):")
-for w in range(8):
-    print(f"  wave {w}: {tw[w,0]-tw[0,0]:7d} .. {tw[w,1]-tw[0,0]:7d}  ({tw[w,1]-tw[w,0]} ticks)")

@@ -18,6 +18,8 @@ The same records for the TRAINED decoder (`tests/golden/trained_decoder_L256.npz
 `scripts/train_synthetic_deepsdf.py`): 16 instances x 2 modes x 9 runs -> trained_c2_inputs.npz / trained_c2_oracle.npz.
 
 Usage:  python tests/golden/make_fullsize_records.py [n_instances] [n_iter] [analytic|trained] [n_jitter]
+(n_iter != 200 writes <prefix>_it<n_iter>_oracle.npz next to the 200-iteration records: short-horizon parity, before
+the chaotic amplification of rounding differences sets in.)
 """
 import os
 import sys
@@ -130,8 +132,9 @@ def main():
     inst = [np.load(os.path.join(SCRATCH, f"inst_{i:03d}.npz")) for i in range(n_inst)]
     keys = ("latent0", "T_ow0", "points_w", "T_wc", "rays_fg", "rays_bg", "depth_fg", "depth_bg", "cube_radius",
             "z_true", "T_wo_true")
-    np.savez_compressed(os.path.join(HERE, PREFIX + "_inputs.npz"),
-                        **{k: np.stack([np.asarray(a[k]) for a in inst]) for k in keys})
+    if n_iter == 200:
+        np.savez_compressed(os.path.join(HERE, PREFIX + "_inputs.npz"),
+                            **{k: np.stack([np.asarray(a[k]) for a in inst]) for k in keys})
     rec = {}
     for m in MODES:
         lat = np.zeros((len(PERTS), n_inst, L), np.float32)
@@ -142,7 +145,9 @@ def main():
                 r = np.load(os.path.join(SCRATCH, f"{i:03d}_{m}_{p}_{n_iter}.npz"))
                 lat[pi, i], Tow[pi, i], itc[pi, i] = r["latent"], r["T_ow"], r["iter_count"]
         rec[f"{m}_latent"], rec[f"{m}_T_ow"], rec[f"{m}_iter_count"] = lat, Tow, itc
-    np.savez_compressed(os.path.join(HERE, PREFIX + "_oracle.npz"), perts=np.array(PERTS), n_iter=n_iter,
+    # the 200-iteration records are the headline fixture; a short-horizon set (e.g. 5 iterations) gets its own name
+    oname = PREFIX + ("_oracle.npz" if n_iter == 200 else f"_it{n_iter}_oracle.npz")
+    np.savez_compressed(os.path.join(HERE, oname), perts=np.array(PERTS), n_iter=n_iter,
                         eps=EPS, **rec)
     print("written", flush=True)
 

@@ -242,7 +242,9 @@ def test_trained_decoder_vs_fp64_oracle(precision):
     from hortimapping_amd import ops
     from hortimapping_amd.decoder import DecoderWeights
     from oracle import hm_oracle as O
-    tol_y, tol_j = {"f32": (2e-6, 2e-5), "f16x3": (2e-6, 2e-5), "f16x3f_f16b": (2e-6, 5e-3), "f16": (3e-4, 2e-2)}[precision]
+    from hortimapping_amd import synthetic as S
+    tol_y, tol_j, kink = {"f32": (2e-6, 2e-5, 1e-6), "f16x3": (2e-6, 2e-5, 1e-6), "f16x3f_f16b": (2e-6, 5e-3, 1e-6),
+                          "f16": (3e-4, 2e-2, 1e-3)}[precision]
     p = trained_params()
     od = O.fold_decoder(p).to(torch.float64)
     dec = DecoderWeights.from_params(p)
@@ -257,10 +259,64 @@ def test_trained_decoder_vs_fp64_oracle(precision):
     pts4[..., :3] = pts
     y, J = ops.decode_batch(dec, lat.cuda(), pts4.cuda(), torch.full((B,), n, dtype=torch.int32).cuda(), mode=1, pose_dim=0)
     y, J = y.cpu().double(), J.cpu().double()
+    Ws, bs = S.fold_weight_norm(p)
+    n_kept = 0
     for b in range(B):
         yo, go = O.decoder_jacobian(od, lat[b], pts[b])
         assert torch.isfinite(y[b]).all() and torch.isfinite(J[b]).all()
         assert float(yo.abs().max()) < 0.05 and float((yo < 0).float().mean()) > 0.05      # queries straddle the surface
         assert float((y[b] - yo).abs().max()) < tol_y
-        assert float((J[b, :, :L] - go[:, :L]).abs().max() / go[:, :L].abs().max()) < tol_j
-        assert float((J[b, :, L:L + 3] - go[:, L:]).abs().max() / go[:, L:].abs().max()) < tol_j
+        # A trained network has hidden units sitting on their ReLU kink for some query (pre-activations are O(0.1) here
+        # and 4096 x 448 of them are evaluated): there the gradient jumps by a finite amount between ANY two arithmetics
+        # that round the pre-activation to different signs.  Compare gradients where the fp64 pre-activations keep a
+        # distance from zero that fp32 rounding cannot bridge, and demand that this is nearly everywhere.
+        u = np.concatenate([np.broadcast_to(lat[b].double().numpy(), (n, L)), pts[b].double().numpy()], axis=1)
+        h, margin = u, np.full(n, np.inf)
+        for l in range(8):
+            if l == 4:
+                h = np.concatenate([h, u], axis=1)
+            pre = h @ Ws[l].astype(np.float64).T + bs[l].astype(np.float64)
+            margin = np.minimum(margin, np.abs(pre).min(axis=1))
+            h = np.maximum(pre, 0)
+        if precision == "f16":       # fp16 rounding of the activations (~1e-4 absolute) crosses a kink for EVERY query:
+            assert float((J[b, :, :L + 3] - torch.cat([go[:, :L], go[:, L:]], 1)).norm() / go.norm()) < 0.05   # norm-wise only
+            n_kept += n
+            continue
+        keep = torch.from_numpy(margin > kink)
+        n_kept += int(keep.sum())
+        assert float((J[b, keep, :L] - go[keep, :L]).abs().max() / go[:, :L].abs().max()) < tol_j
+        assert float((J[b, keep, L:L + 3] - go[keep, L:]).abs().max() / go[:, L:].abs().max()) < tol_j
+    assert n_kept >= 0.9 * B * n, n_kept
+
+
+@pytest.mark.parametrize("mode", ["known", "free"])
+def test_trained_short_horizon_parity(mode, precision):
+    """The trained-decoder instances after FIVE iterations, before two hundred iterations of a kinked (ReLU) objective
+    have amplified every rounding difference: latent and pose of each instance against the oracle record, within
+    max(floor, K_NOISE x the deviation of that instance's eight perturbed oracle runs) -- in pose_known mode the
+    median bound is ~7e-5 on latent entries of size 0.02.  (Free pose is ill-conditioned from the first solve with
+    this decoder: the oracle's own T_ow moves by up to 0.5 under a 1e-7 input perturbation, so that mode only catches
+    gross errors.)"""
+    import os
+    from golden_util import GOLDEN_DIR
+    from hortimapping_amd import optimizer as HO, workloads as W
+    from hortimapping_amd.decoder import DecoderWeights
+    if precision not in ("f32", "f16x3"):
+        pytest.skip("fp32-class arithmetics only")
+    rec = np.load(os.path.join(GOLDEN_DIR, "trained_c2_it5_oracle.npz"))
+    n_iter = int(rec["n_iter"])
+    dec = DecoderWeights.from_params(trained_params())
+    dec.set_precision(precision)
+    res = HO.optimize_batch(dec, W.c2_opt_cfg(max_iter=n_iter), fullsize_instances(mode == "known", "trained"))
+    lat = np.stack([r.latent.numpy() for r in res])
+    T = np.stack([r.T_ow.numpy() for r in res])
+    lat_o, T_o = rec[f"{mode}_latent"], rec[f"{mode}_T_ow"]
+    assert all(r.iter_count == n_iter for r in res) and np.all(rec[f"{mode}_iter_count"] == n_iter)
+    noise_l = np.abs(lat_o[1:] - lat_o[0]).max(axis=(0, 2))
+    noise_T = np.abs(T_o[1:] - T_o[0]).max(axis=(0, 2, 3))
+    dl = np.abs(lat - lat_o[0]).max(axis=1)
+    dT = np.abs(T - T_o[0]).max(axis=(1, 2))
+    bad = [i for i in range(len(res)) if dl[i] > max(1e-5, K_NOISE * noise_l[i]) or dT[i] > max(1e-5, K_NOISE * noise_T[i])]
+    print(f"\n{precision} pose_{mode}, {n_iter} iterations: max |d latent| median {np.median(dl):.2e} (oracle noise "
+          f"{np.median(noise_l):.2e}), max |d T_ow| median {np.median(dT):.2e} (noise {np.median(noise_T):.2e}); outside: {bad}")
+    assert len(bad) <= N_OUTLIER, bad
