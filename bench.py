@@ -150,6 +150,8 @@ def parse_args(argv=None):
                     help="decoder weights: the analytic synthetic fruit (default, BASELINE workload) or the weights learnt "
                          "by scripts/train_synthetic_deepsdf.py (tests/golden/trained_decoder_L256.npz, L = 256 only)")
     ap.add_argument("--stub-cpu", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--share-gpu", action="store_true", help=argparse.SUPPRESS)   # tests: N ranks on ONE GPU over gloo
+    ap.add_argument("--dump-records", default="", help=argparse.SUPPRESS)         # tests: rank 0 saves the gathered records
     return ap.parse_args(argv)
 
 
@@ -165,7 +167,10 @@ def main(argv=None, emit=True):
     from hortimapping_amd import distributed as D
     import torch.distributed as dist
     stub = args.stub_cpu
-    rank, local_rank, world = D.init_from_env(backend="gloo" if stub else None)
+    share = args.share_gpu            # test rigs with one GPU: every rank runs the REAL job on cuda:0, collectives over gloo
+    rank, local_rank, world = D.init_from_env(backend="gloo" if (stub or share) else None)
+    if share:
+        local_rank = 0
     if args.gpus != world:
         if world > 1 or args.gpus > 1:
             raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run "
@@ -308,6 +313,8 @@ def main(argv=None, emit=True):
     dt, ms_tot, n_launch, allrec = measure(args.precision, args.steps, args.warmup)
 
     if rank == 0:
+        if args.dump_records:
+            torch.save(allrec.cpu(), args.dump_records)
         lat, T, it, st = D.unpack_records(allrec.cpu(), L)
         assert lat.shape[0] == n_total, (lat.shape, n_total)
         assert torch.isfinite(lat).all() and torch.isfinite(T).all(), "non-finite result"
@@ -340,6 +347,8 @@ def main(argv=None, emit=True):
                 "parallelism": f"instances sharded over {world} GPU(s), one RCCL all-gather of results per step",
             },
         }
+        if share:
+            out["test_mode"] = "all ranks share one GPU, collectives over gloo: NOT a measurement"
         if stub:
             out["stub"] = "rank logic only (gloo, CPU stand-in for the GPU optimisation): NOT a measurement"
         else:

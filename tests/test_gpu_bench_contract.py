@@ -51,3 +51,40 @@ def test_bench_strong_scaling_configs3_rank_share():
     assert c["instances_total"] == 512 and c["instances_per_gpu"] == 512 and c["chunk"] == 256 and c["iterations"] == 6
     assert abs(d["value"] - 512 / (d["ms_per_step"] * 1e-3)) < 0.02 * d["value"]
     assert d["roofline"]["launches"] == 2 * 6                          # two chunks x six iterations were profiled
+
+
+def test_bench_two_ranks_real_job_on_one_gpu():
+    """bench.py's N > 1 branch with the REAL optimisation: two ranks launched like the driver does (one process per
+    rank, RANK / WORLD_SIZE / MASTER_* in the environment), both on this box's single GPU with the collectives over gloo
+    (`--share-gpu`; RCCL cannot place two ranks on one device).  Checks what the 8-GPU run relies on: the shard plan,
+    per-rank instance generation, the record all-gather in instance order, the MAX all-reduce of the time, one JSON line
+    from rank 0 only -- and that the gathered results equal a single-rank run of the same 2 x 4 instances."""
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    common = ["--steps", "1", "--warmup", "0", "--batch", "4", "--latent", "32", "--iters", "5", "--no-exact",
+              "--no-cpu-baseline"]
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-gpu",
+                                       "--dump-records", os.path.join(ROOT, "gpurun_out", "tmp_records_2rank.pt")] + common,
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=ROOT))
+    outs = [p.communicate(timeout=900) for p in procs]
+    assert all(p.returncode == 0 for p in procs), [o[1][-1500:] for o in outs]
+    lines0 = [l for l in outs[0][0].splitlines() if l.startswith("{")]
+    assert len(lines0) == 1 and not [l for l in outs[1][0].splitlines() if l.startswith("{")]
+    d = json.loads(lines0[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["instances_total"] == 8 and "test_mode" in d
+    assert abs(d["value"] - 8 / (d["ms_per_step"] * 1e-3)) < 0.02 * d["value"]
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--dump-records",
+                          os.path.join(ROOT, "gpurun_out", "tmp_records_1rank.pt"), "--steps", "1", "--warmup", "0", "--batch",
+                          "8", "--latent", "32", "--iters", "5", "--no-exact", "--no-cpu-baseline"],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert one.returncode == 0, one.stderr[-1500:]
+    import torch
+    a = torch.load(os.path.join(ROOT, "gpurun_out", "tmp_records_2rank.pt"))
+    b = torch.load(os.path.join(ROOT, "gpurun_out", "tmp_records_1rank.pt"))
+    assert a.shape == b.shape == (8, 32 + 18) and torch.equal(a, b)          # same instances, same order, same bits
