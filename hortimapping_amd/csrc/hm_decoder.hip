@@ -375,8 +375,18 @@ __global__ void k_latent_bias(const DecoderDev dec, const float* __restrict__ la
   const int f = threadIdx.x & (HID - 1);
   const bool second = threadIdx.x >= HID;
   const float* wT = second ? dec.w4z : dec.w0z;   // stored transposed [L][512] for coalescing
+  // one serial fma chain per output (the summation order is part of the bitwise contract); what costs time is the
+  // latency of the 256 dependent-looking loads, so fetch 32 weights ahead of the chain that consumes them
   float s = 0.f;
-  for (int j = 0; j < L; ++j) s = fmaf(wT[(size_t)j * HID + f], z[j], s);
+  int j = 0;
+  for (; j + 32 <= L; j += 32) {
+    float wv[32];
+#pragma unroll
+    for (int u = 0; u < 32; ++u) wv[u] = wT[(size_t)(j + u) * HID + f];
+#pragma unroll
+    for (int u = 0; u < 32; ++u) s = fmaf(wv[u], z[j + u], s);
+  }
+  for (; j < L; ++j) s = fmaf(wT[(size_t)j * HID + f], z[j], s);
   s += second ? dec.b4[f] : dec.b0[f];
   (second ? c4 : c0)[(size_t)b * HID + f] = s;
 }
