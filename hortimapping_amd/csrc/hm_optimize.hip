@@ -313,7 +313,9 @@ extern "C" int hm_optimize_batch(hm_workspace_s* ws, const hm_opt_cfg* cfg, cons
   for (int it = 0; it < cfg->max_iter; ++it) {
     if (n_checks > LAG && it % check_every == 0) {
       const int slot = (n_checks - 1 - LAG) % N_ACT;
-      if (hipEventQuery(ws->ev_act[slot]) == hipSuccess && ws->h_act_count[slot] == 0) break;
+      const hipError_t q = hipEventQuery(ws->ev_act[slot]);
+      (void)hipGetLastError();                      // hipErrorNotReady is an answer, not a failure: do not leave it behind
+      if (q == hipSuccess && ws->h_act_count[slot] == 0) break;
     }
     rc = launch_latent_bias(ws->dec, bt->d_latent, L, ws->active, B, ws->c0, ws->c4, st);
     if (rc) return rc;
