@@ -48,17 +48,58 @@ __device__ __forceinline__ f32x16 zero16h() {
   return z;
 }
 
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// Epilogue arithmetic.  The epilogues run between two barriers with the matrix pipe idle and are VALU-bound (64
+// accumulator values per lane and stage), so every value is kept to ~6 instructions: packed fp32 fma / mul, packed
+// conversions, and the low part by ONE mixed-precision fma per value that reads the fp16 high part directly,
+//     lo = f16( hi * -2^11 + v * 2^11 )          (v_fma_mixlo/hi_f16: exact fp32 fma, one rounding to fp16)
+// which is bit-identical to f16((v - f32(hi)) * 2^11): the difference and both scalings are exact.
+__device__ __forceinline__ uint32_t lo_pair(uint32_t hpk, float s0, float s1) {
+  uint32_t d;
+  const float c = -LO_SCALE;
+  asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mixhi_f16 %0, %1, %2, %4 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+      : "=&v"(d) : "v"(hpk), "s"(c), "v"(s0), "v"(s1));
+  return d;
+}
+
+// range guard: running maximum of |hi| as packed fp16 (an overflowing value converts to +-inf and sticks)
+__device__ __forceinline__ void track_max(f16x2& xm, uint32_t h0, uint32_t h1, bool take_abs) {
+  if (take_abs) { h0 &= 0x7fff7fffu; h1 &= 0x7fff7fffu; }
+  f16x2 a, b;
+  __builtin_memcpy(&a, &h0, 4);
+  __builtin_memcpy(&b, &h1, 4);
+  xm = __builtin_elementwise_max(xm, __builtin_elementwise_max(a, b));
+}
+
 // split 4 consecutive-row values into the hi / scaled-lo fp16 planes (8 bytes each)
-__device__ __forceinline__ void split_store(f16x4* xh4, f16x4* xl4, int idx, const float (&v)[4]) {
-  f16x4 h, l;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const _Float16 hj = (_Float16)v[j];
-    h[j] = hj;
-    l[j] = (_Float16)((v[j] - (float)hj) * LO_SCALE);
-  }
-  xh4[idx] = h;
-  xl4[idx] = l;
+template <bool ABS>
+__device__ __forceinline__ void split_store(f16x4* xh4, f16x4* xl4, int idx, const f32x2 a, const f32x2 b, f16x2& xm) {
+  const f16x2 ha = __builtin_convertvector(a, f16x2), hb = __builtin_convertvector(b, f16x2);
+  const f32x2 sa = a * LO_SCALE, sb = b * LO_SCALE;
+  uint32_t hau, hbu;
+  __builtin_memcpy(&hau, &ha, 4);
+  __builtin_memcpy(&hbu, &hb, 4);
+  const uint2 hh = {hau, hbu};
+  const uint2 ll = {lo_pair(hau, sa[0], sa[1]), lo_pair(hbu, sb[0], sb[1])};
+  track_max(xm, hau, hbu, ABS);
+  reinterpret_cast<uint2*>(xh4)[idx] = hh;
+  reinterpret_cast<uint2*>(xl4)[idx] = ll;
+}
+
+// ReLU masks: bit of the k-th value an epilogue processes sits at position 31 - k of its 32-bit word (the forward
+// epilogue shifts the word left and adds the compare result: v_cmp_gt_f32 + v_addc_co_u32, two instructions per value).
+// Processing order everywhere: g (row group of 8) outer, nb (query block) inner, j (row within the group's 4) innermost.
+__device__ __forceinline__ constexpr int mask_pos(int g, int nb, int j) { return 31 - ((g * 2 + nb) * 4 + j); }
+__device__ __forceinline__ void mask_push(uint32_t& bits, float val) {
+  asm("v_cmp_gt_f32 vcc, %1, 0\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(bits) : "v"(val) : "vcc");
+}
+// x where the mask bit is set, +0 elsewhere (v_bfe_i32 + v_and_b32)
+__device__ __forceinline__ float mask_keep(float x, uint32_t bits, int pos) {
+  const uint32_t m = (uint32_t)__builtin_amdgcn_sbfe((int)bits, pos, 1);
+  return __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, x) & m);
 }
 
 // K loop.  Weights (A, from L2) are fetched TWO K-steps ahead into a ring of three statically named register sets,
@@ -294,12 +335,12 @@ __global__ __launch_bounds__(512, 2) void k_decoder_h(const DecodeArgsH a) {
   // stage 0 input: rows 0..2 = xyz, rows 3..15 = 0  (groups 0 and 1)
   if (tid < TQ) {
     const f32x4 p = pts4[qbase + tid];
-    const float v0[4] = {p[0], p[1], p[2], 0.f};
-    const float vz[4] = {0.f, 0.f, 0.f, 0.f};
-    split_store(xh4, xl4, (0 * TQ + tid) * 2 + 0, v0);
-    split_store(xh4, xl4, (0 * TQ + tid) * 2 + 1, vz);
-    split_store(xh4, xl4, (1 * TQ + tid) * 2 + 0, vz);
-    split_store(xh4, xl4, (1 * TQ + tid) * 2 + 1, vz);
+    const f32x2 zz = {0.f, 0.f};
+    f16x2 untracked = {(_Float16)0.f, (_Float16)0.f};     // query coordinates: far inside the fp16 range by contract
+    split_store<false>(xh4, xl4, (0 * TQ + tid) * 2 + 0, f32x2{p[0], p[1]}, f32x2{p[2], 0.f}, untracked);
+    split_store<false>(xh4, xl4, (0 * TQ + tid) * 2 + 1, zz, zz, untracked);
+    split_store<false>(xh4, xl4, (1 * TQ + tid) * 2 + 0, zz, zz, untracked);
+    split_store<false>(xh4, xl4, (1 * TQ + tid) * 2 + 1, zz, zz, untracked);
   }
 
   uint2 mk0 = {0, 0}, mk1 = {0, 0}, mk2 = {0, 0}, mk3 = {0, 0}, mk4 = {0, 0}, mk5 = {0, 0}, mk6 = {0, 0},
@@ -311,7 +352,7 @@ __global__ __launch_bounds__(512, 2) void k_decoder_h(const DecodeArgsH a) {
   // part becomes inf, the next ReLU turns the resulting NaN into 0 and the network would silently compute garbage.
   // A tile that overflowed is poisoned instead (NaN sdf, NaN Jacobian rows), which the solver reports as
   // HM_STATUS_SOLVE_FAILED; the exact fp32 arithmetic (precision 0) has no such limit.
-  float xmax = 0.f;
+  f16x2 xm2 = {(_Float16)0.f, (_Float16)0.f};   // range guard: running max of |hi|, see track_max
   const float* cbias0 = a.c0 + (size_t)b * HID;
   const float* cbias4 = a.c4 + (size_t)b * HID;
   // stage all forward biases in LDS: the epilogues then never wait on global memory
@@ -415,25 +456,23 @@ __global__ __launch_bounds__(512, 2) void k_decoder_h(const DecodeArgsH a) {
         if (!use) continue;
         const int mb = sl == 0 ? mb0 : mb1;
         uint32_t bits = 0;
+        const f32x2 us2 = {us, us};
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const int f4 = mb * 32 + 8 * g + 4 * hi;
+          const f32x2 b01 = {bv[sl][g][0], bv[sl][g][1]}, b23 = {bv[sl][g][2], bv[sl][g][3]};
 #pragma unroll
           for (int nb = 0; nb < 2; ++nb) {
-            float v[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              const float val = fmaf(acc[sl][nb][4 * g + j], us, bv[sl][g][j]);
-              const bool pos = val > 0.f;
-              bits |= (pos ? 1u : 0u) << (nb * 16 + 4 * g + j);
-              v[j] = pos ? val : 0.f;
-            }
-            xmax = fmaxf(xmax, fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])));
+            const f32x2 a01 = {acc[sl][nb][4 * g + 0], acc[sl][nb][4 * g + 1]};
+            const f32x2 a23 = {acc[sl][nb][4 * g + 2], acc[sl][nb][4 * g + 3]};
+            const f32x2 v01 = __builtin_elementwise_fma(a01, us2, b01), v23 = __builtin_elementwise_fma(a23, us2, b23);
+            mask_push(bits, v01[0]); mask_push(bits, v01[1]); mask_push(bits, v23[0]); mask_push(bits, v23[1]);
+            f32x2 r01 = {fmaxf(v01[0], 0.f), fmaxf(v01[1], 0.f)}, r23 = {fmaxf(v23[0], 0.f), fmaxf(v23[1], 0.f)};
             if (g == 3 && epi == EPI_FWD3 && mb == mbx && hi == 1) {
               const f32x4 p = pts4[qbase + nb * 32 + qa];
-              v[1] = p[0]; v[2] = p[1]; v[3] = p[2];
+              r01[1] = p[0]; r23[0] = p[1]; r23[1] = p[2];
             }
-            split_store(xh4, xl4, ((f4 >> 3) * TQ + nb * 32 + qa) * 2 + hi, v);
+            split_store<false>(xh4, xl4, ((f4 >> 3) * TQ + nb * 32 + qa) * 2 + hi, r01, r23, xm2);
           }
         }
         if (sl == 0) mk.x = bits; else mk.y = bits;
@@ -456,7 +495,7 @@ __global__ __launch_bounds__(512, 2) void k_decoder_h(const DecodeArgsH a) {
 #pragma unroll
           for (int j = 0; j < 4; ++j) { part = fmaf(x[4 + j], w1[j], part); }
         }
-        if (__any(!(xmax < 65504.f))) part = __builtin_nanf("");
+        if (__any(!(fmaxf((float)xm2[0], (float)xm2[1]) < 65504.f))) part = __builtin_nanf("");
         sc[w * 64 + lane] = part;
         __syncthreads();
         float a8 = 0.f;
@@ -485,9 +524,12 @@ __global__ __launch_bounds__(512, 2) void k_decoder_h(const DecodeArgsH a) {
               const float dy = nb == 0 ? dyA : dyB;
               float v[4];
 #pragma unroll
-              for (int j = 0; j < 4; ++j) v[j] = ((bits >> (nb * 16 + 4 * g + j)) & 1u) ? dy * wv[j] : 0.f;
+              for (int j = 0; j < 4; ++j) v[j] = mask_keep(dy * wv[j], bits, mask_pos(g, nb, j));
               if (BW1) hi_store(xh4, ((f4 >> 3) * TQ + nb * 32 + qa) * 2 + hi, v);
-              else split_store(xh4, xl4, ((f4 >> 3) * TQ + nb * 32 + qa) * 2 + hi, v);
+              else {
+                f16x2 unused = xm2;      // dy * w8 cannot overflow where the forward did not: not tracked
+                split_store<false>(xh4, xl4, ((f4 >> 3) * TQ + nb * 32 + qa) * 2 + hi, f32x2{v[0], v[1]}, f32x2{v[2], v[3]}, unused);
+              }
             }
           }
         }
@@ -528,13 +570,23 @@ __global__ __launch_bounds__(512, 2) void k_decoder_h(const DecodeArgsH a) {
           const int f4 = mb * 32 + 8 * g + 4 * hi;
 #pragma unroll
           for (int nb = 0; nb < 2; ++nb) {
-            float v[4];
+            const f32x2 us2 = {us, us};
+            const f32x2 p01 = f32x2{acc[sl][nb][4 * g + 0], acc[sl][nb][4 * g + 1]} * us2;
+            const f32x2 p23 = f32x2{acc[sl][nb][4 * g + 2], acc[sl][nb][4 * g + 3]} * us2;
+            const f32x2 v01 = {mask_keep(p01[0], bits, mask_pos(g, nb, 0)), mask_keep(p01[1], bits, mask_pos(g, nb, 1))};
+            const f32x2 v23 = {mask_keep(p23[0], bits, mask_pos(g, nb, 2)), mask_keep(p23[1], bits, mask_pos(g, nb, 3))};
+            if (BW1) {
+              const float v[4] = {v01[0], v01[1], v23[0], v23[1]};
+              f16x4 hq;
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-              v[j] = ((bits >> (nb * 16 + 4 * g + j)) & 1u) ? acc[sl][nb][4 * g + j] * us : 0.f;
-            xmax = fmaxf(xmax, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
-            if (BW1) hi_store(xh4, ((f4 >> 3) * TQ + nb * 32 + qa) * 2 + hi, v);
-            else split_store(xh4, xl4, ((f4 >> 3) * TQ + nb * 32 + qa) * 2 + hi, v);
+              for (int j = 0; j < 4; ++j) hq[j] = (_Float16)v[j];
+              uint2 hu;
+              __builtin_memcpy(&hu, &hq, 8);
+              track_max(xm2, hu.x, hu.y, true);
+              xh4[((f4 >> 3) * TQ + nb * 32 + qa) * 2 + hi] = hq;
+            } else {
+              split_store<true>(xh4, xl4, ((f4 >> 3) * TQ + nb * 32 + qa) * 2 + hi, v01, v23, xm2);
+            }
           }
         }
       }
@@ -561,7 +613,7 @@ __global__ __launch_bounds__(512, 2) void k_decoder_h(const DecodeArgsH a) {
 
   if (a.trace != nullptr && blockIdx.x == 0 && tid == 0) a.trace[n_stage * 4] = clock64();
   if (MODE == 0) return;
-  if (__any(!(xmax < 65504.f))) gx0 = __builtin_nanf("");
+  if (__any(!(fmaxf((float)xm2[0], (float)xm2[1]) < 65504.f))) gx0 = __builtin_nanf("");
   sc[(w * 4 + 0) * 64 + lane] = gx0;
   sc[(w * 4 + 1) * 64 + lane] = gx1;
   sc[(w * 4 + 2) * 64 + lane] = gx2;
