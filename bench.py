@@ -377,6 +377,13 @@ def main(argv=None, emit=True):
                                   "ms_per_step": o2["ms_per_step"], "roofline": o2["roofline"],
                                   "decoder_weights": o2["config"]["decoder_weights"],
                                   "parity": "profiles/r02_parity_trained_*.txt (per-instance vs the CPU oracle)"}
+        # the same job with 256 instances resident per GPU (the chunk size of configs[3]): the ragged last tile rounds of
+        # the render-chain launches and the per-instance solve amortise over more instances
+        o3 = main(["--steps", "1", "--warmup", "1", "--iters", str(args.iters), "--total", "256", "--batch", "256", "--precision",
+                   args.precision, "--no-exact", "--no-cpu-baseline"], emit=False)
+        out["batch_256"] = {"value": o3["value"], "unit": o3["unit"], "steps": 1, "dtype": o3["dtype"],
+                            "ms_per_step": o3["ms_per_step"], "instances_per_gpu": 256,
+                            "note": "64 distinct synthetic peppers replicated cyclically; not the BASELINE configuration"}
     if rank == 0:
         if not stub and not args.no_cpu_baseline and world == 1:   # N = 1 only; other ranks would idle in the barrier
             out["cpu_baseline"] = cpu_baseline(params, cfg, dicts[0], kind)
