@@ -84,3 +84,31 @@ def test_pose_init_and_cleaning():
     assert abs(np.cbrt(np.linalg.det(T[:3, :3])) - max(size / (2 * 0.064), 0.5)) < 1e-9
     _, _, _, ok2 = get_pose_init(fruit * 10, bg)                                # 0.8 m object: rejected (utils.py:431-433)
     assert not ok2
+
+
+def test_depth_filters_of_the_challenge_loader():
+    """The two OpenCV calls of the challenge data loader (dataloader.py:50-53,66-71) as restated in datasets.py, against
+    their definitions written out pixel by pixel: cv2.erode with an 11 x 11 rectangle = minimum over the in-image part of
+    the window; cv2.bilateralFilter(d=3): radius-1 circular neighbourhood = the 5-point cross, Gaussian weights in range
+    (sigma 15) and space (sigma 15), reflect-101 border.  (OpenCV itself is not in this image: cv2's float path
+    evaluates the range weight through an interpolated table, so its output agrees with the formula to ~1e-4 relative.)"""
+    from hortimapping_amd.datasets import _bilateral_3, _erode_11
+    rs = np.random.RandomState(0)
+    d = (0.3 + 0.7 * rs.rand(23, 31)).astype(np.float32)
+    d[rs.rand(23, 31) < 0.1] = 0.0
+    e = _erode_11(d)
+    for (y, x) in [(0, 0), (5, 7), (22, 30), (11, 0), (0, 15), (12, 16)]:
+        assert e[y, x] == d[max(0, y - 5):y + 6, max(0, x - 5):x + 6].min()
+    assert e.dtype == d.dtype and e.shape == d.shape
+    f = _bilateral_3(d)
+    idx = lambda i, n: -i if i < 0 else (2 * n - 2 - i if i >= n else i)              # reflect-101
+    for (y, x) in [(0, 0), (5, 7), (22, 30), (11, 0), (0, 15)]:
+        num = den = 0.0
+        for dy, dx in ((0, 0), (-1, 0), (1, 0), (0, -1), (0, 1)):
+            v = float(d[idx(y + dy, 23), idx(x + dx, 31)])
+            w = np.exp(-(v - float(d[y, x])) ** 2 / (2 * 15.0 ** 2)) * np.exp(-(dy * dy + dx * dx) / (2 * 15.0 ** 2))
+            num += w * v
+            den += w
+        assert abs(f[y, x] - num / den) < 1e-6
+    c = np.full((9, 9), 0.42, np.float32)
+    assert np.allclose(_bilateral_3(c), c, atol=1e-7) and np.array_equal(_erode_11(c), c)
