@@ -70,15 +70,19 @@ def _declare(lib):
     if getattr(lib, "_hm_mesh_declared", False):
         return
     vp, ci = ctypes.c_void_p, ctypes.c_int
-    lib.hm_extract_surface.restype = ci
-    lib.hm_extract_surface.argtypes = [ci, vp, ci, ctypes.c_float, ctypes.c_float, vp, vp, vp, ci, vp]
+    for fn in (lib.hm_extract_surface, lib.hm_extract_surface_mc):
+        fn.restype = ci
+        fn.argtypes = [ci, vp, ci, ctypes.c_float, ctypes.c_float, vp, vp, vp, ci, vp]
     lib._hm_mesh_declared = True
 
 
-def extract_surface(sdf: torch.Tensor, cube_radius: float, level: float = 0.0, max_tris: int = 0):
-    """sdf (B, n, n, n) cuda f32 -> list of (T_b, 3, 3) float32 triangle soups (object frame)."""
+def extract_surface(sdf: torch.Tensor, cube_radius: float, level: float = 0.0, max_tris: int = 0, method: str = "mc"):
+    """sdf (B, n, n, n) cuda f32 -> list of (T_b, 3, 3) float32 triangle soups (object frame).  `method`: "mc" =
+    marching cubes (the reference's algorithm family, `utils.py:573`: vertices exactly on the grid-edge crossings),
+    "mt" = marching tetrahedra (finer triangulation with extra vertices on cell diagonals)."""
     lib = _lib.lib()
     _declare(lib)
+    fn = {"mc": lib.hm_extract_surface_mc, "mt": lib.hm_extract_surface}[method]
     assert sdf.is_cuda and sdf.dtype == torch.float32 and sdf.dim() == 4
     sdf = sdf.contiguous()
     B, n = sdf.shape[0], sdf.shape[1]
@@ -88,8 +92,8 @@ def extract_surface(sdf: torch.Tensor, cube_radius: float, level: float = 0.0, m
         offsets = torch.empty(B, ncell, dtype=torch.int32, device=sdf.device)
         count = torch.zeros(B, dtype=torch.int32, device=sdf.device)
         tris = torch.empty(B, cap, 9, dtype=torch.float32, device=sdf.device)
-        rc = lib.hm_extract_surface(B, sdf.data_ptr(), n, float(level), float(cube_radius), offsets.data_ptr(),
-                                    count.data_ptr(), tris.data_ptr(), cap, torch.cuda.current_stream().cuda_stream)
+        rc = fn(B, sdf.data_ptr(), n, float(level), float(cube_radius), offsets.data_ptr(),
+                count.data_ptr(), tris.data_ptr(), cap, torch.cuda.current_stream().cuda_stream)
         _lib.check(rc, "hm_extract_surface")
         cnt = count.cpu().numpy()
         if int(cnt.max()) <= cap:
@@ -114,7 +118,8 @@ def weld(soup: np.ndarray):
 class MeshExtractor(object):
     """Drop-in for `wild_completion.mesher.MeshExtractor` (mesher.py:5-32)."""
 
-    def __init__(self, decoder, code_len=64, voxels_dim=64, cube_radius=1.0):
+    def __init__(self, decoder, code_len=64, voxels_dim=64, cube_radius=1.0, method="mc"):
+        self.method = method
         self.decoder = as_weights(decoder)
         self.code_len = code_len
         self.voxels_dim = int(voxels_dim)
@@ -138,7 +143,7 @@ class MeshExtractor(object):
         return y[:, :n3].reshape(B, n, n, n)
 
     def extract_meshes(self, latents: torch.Tensor) -> List[TriangleMesh]:
-        soups = extract_surface(self.decode_grids(latents), self.cube_radius)
+        soups = extract_surface(self.decode_grids(latents), self.cube_radius, method=self.method)
         return [TriangleMesh(*weld(s)) for s in soups]
 
     def extract_mesh_from_code(self, code):

@@ -199,6 +199,10 @@ int hm_debug_huber(const float* d_res, int n, float threshold, float* d_rho, flo
  * were emitted); d_tris [B][max_tris][9]: xyz of the three vertices, object frame, grid [-1,1]^3 scaled by cube_radius. */
 int hm_extract_surface(int B, const float* d_sdf, int n, float level, float cube_radius, int* d_offsets,
                        int* d_tri_count, float* d_tris, int max_tris, void* stream);
+/* the same with marching cubes: vertices exactly the grid-edge crossings (the vertex set of the reference's
+ * scikit-image call, utils.py:573), at most 5 triangles per cell from a table generated at load time */
+int hm_extract_surface_mc(int B, const float* d_sdf, int n, float level, float cube_radius, int* d_offsets,
+                       int* d_tri_count, float* d_tris, int max_tris, void* stream);
 
 /* ---- evaluation primitive: nearest-neighbour distances, the query under ChamferDistance
  * (metrics_3d/chamfer_distance.py:16-26) and PrecisionRecall (metrics_3d/precision_recall.py:13-50), which use an

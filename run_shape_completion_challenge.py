@@ -6,7 +6,7 @@ Same option / YAML schema / dataset layout / result files / printed metrics as t
 F-score at 5 mm, timing, iterations), with all fruits of the split optimised in one batched call
 (`pose_known=True`, T_ow = identity, :207-218).  `baseline_name: DeepSDF` selects the shape-only optimiser (:215-216).
 Result meshes (`results/<run_name>/<split>/<fid>.ply`) are the same level set the reference meshes with scikit-image's
-marching cubes, extracted by marching tetrahedra on the GPU: finer triangulation, same surface (see
+marching cubes, extracted by marching cubes on the GPU: the same grid-edge vertices (see
 test_wild_completion.py); the metrics are computed from points sampled on it, as in the reference (:239-247).
 """
 import os

@@ -9,10 +9,10 @@ Background submap, ids below `begin_submap`, submaps without a matched frame (`g
 initialisation, and the post-hoc outlier rejection on scale / pitch / roll.
 
 Output contract of the completed meshes (`submaps_complete/<name>.ply`): the zero level set of the decoded SDF grid the
-reference hands to scikit-image's marching cubes (`wild_completion/utils.py:565-588`), extracted here by marching
-tetrahedra on the GPU -- the same piecewise-linear surface through the same grid-edge crossings, with a different
-(finer) triangulation: vertex and face counts differ from the reference's files, the surface does not
-(`tests/test_gpu_mesher.py`, `oracle/level_set.py`).
+reference hands to scikit-image's marching cubes (`wild_completion/utils.py:565-588`), extracted here by marching cubes
+on the GPU (`hm_extract_surface_mc`): the vertices are exactly the grid-edge crossings any marching-cubes variant
+produces; the triangulation of ambiguous cells comes from a generated table and may differ from scikit-image's
+Lewiner tables (`tests/test_gpu_mesher.py`, `oracle/level_set.py`).
 
 `deepsdf_dir` may be a DeepSDF experiment directory (specs.json + ModelParameters + LatentCodes, as in the reference)
 or `synthetic:latent=<L>,seed=<s>[,r0=<r>]` for the analytic decoder (the reference tree ships no weights)."""

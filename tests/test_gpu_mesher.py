@@ -1,4 +1,5 @@
-"""GPU tests of the mesh-extraction row: grid decode + marching tetrahedra through the C ABI."""
+"""GPU tests of the mesh-extraction row: grid decode + marching cubes (default) / marching tetrahedra
+through the C ABI."""
 import numpy as np
 import pytest
 import torch
@@ -13,7 +14,8 @@ def _edges_ok(faces):
     return cnt
 
 
-def test_surface_of_analytic_sphere():
+@pytest.mark.parametrize("method", ["mc", "mt"])
+def test_surface_of_analytic_sphere(method):
     """sdf = |x| - r on a regular 33^3 grid: watertight, genus 0, outward oriented, area/volume of a sphere."""
     from hortimapping_amd.mesher import TriangleMesh, extract_surface, weld
     n, R, r = 33, 0.08, 0.0503
@@ -21,7 +23,7 @@ def test_surface_of_analytic_sphere():
     X, Y, Z = torch.meshgrid(ax, ax, ax, indexing="ij")
     sdf = (torch.sqrt(X * X + Y * Y + Z * Z) - r).float()
     grids = torch.stack([sdf, sdf - 0.01]).cuda()                       # second instance: radius 0.06
-    soups = extract_surface(grids, R)
+    soups = extract_surface(grids, R, method=method)
     for soup, rad in zip(soups, (0.0503, 0.0603)):
         v, f = weld(soup)
         m = TriangleMesh(v, f)
@@ -34,7 +36,27 @@ def test_surface_of_analytic_sphere():
         assert abs(m.area() / (4 * np.pi * rad ** 2) - 1) < 0.02
 
 
-def test_mesh_extractor_drop_in():
+def test_marching_cubes_on_ambiguous_configurations():
+    """Random sdf grids hit every one of the 256 corner configurations, including the ambiguous faces and the saddle
+    cells: the generated triangle table must still give a closed, consistently oriented surface (every edge in exactly
+    two faces, with opposite directions), and per-cell triangle counts of at most 5."""
+    from hortimapping_amd.mesher import extract_surface, weld
+    g = torch.Generator().manual_seed(11)
+    grids = (torch.rand(2, 12, 12, 12, generator=g) - 0.5)
+    grids[:, 0, :, :] = grids[:, -1, :, :] = grids[:, :, 0, :] = grids[:, :, -1, :] = grids[:, :, :, 0] = grids[:, :, :, -1] = 1.0
+    soups = extract_surface(grids.cuda().float(), 1.0, method="mc")          # positive shell: nothing crosses the boundary
+    for soup in soups:
+        v, f = weld(soup)
+        assert f.shape[0] > 1000 and f.shape[0] <= 5 * 11 ** 3
+        assert np.all(_edges_ok(f) == 2)
+        de = np.concatenate([f[:, [0, 1]], f[:, [1, 2]], f[:, [2, 0]]], axis=0)
+        key = de[:, 0].astype(np.int64) * (v.shape[0] + 1) + de[:, 1]
+        rev = de[:, 1].astype(np.int64) * (v.shape[0] + 1) + de[:, 0]
+        assert np.unique(key).shape[0] == key.shape[0] and np.array_equal(np.sort(key), np.sort(rev))   # each directed edge once, its reverse once
+
+
+@pytest.mark.parametrize("method", ["mc", "mt"])
+def test_mesh_extractor_drop_in(method):
     """MeshExtractor(decoder, code_len, voxels_dim, cube_radius): voxels_dim = int(2 * 0.08 * 1e3 / 4.0) = 40
     (test_wild_completion.py:69-71), batched over instances; vertices lie on the decoder's zero level set at the
     positions the (sheared) reference grid was sampled at."""
@@ -43,7 +65,7 @@ def test_mesh_extractor_drop_in():
     from hortimapping_amd.mesher import MeshExtractor, create_voxel_grid
     p = S.make_synthetic_decoder(32, seed=1, r0=0.04, aniso=(1.0, 0.75, 1.3))
     dec = DecoderWeights.from_params(p)
-    mx = MeshExtractor(dec, code_len=32, voxels_dim=40, cube_radius=0.08)
+    mx = MeshExtractor(dec, code_len=32, voxels_dim=40, cube_radius=0.08, method=method)
     lat = 0.05 * torch.randn(3, 32, generator=torch.Generator().manual_seed(0))
     meshes = mx.extract_meshes(lat)
     assert len(meshes) == 3
@@ -52,7 +74,7 @@ def test_mesh_extractor_drop_in():
     ref = U.decode_sdf(dec, lat[1], pts).cpu().reshape(40, 40, 40)
     assert float((grids[1] - ref).abs().max()) == 0.0                      # batched grid decode == single decode
     for m in meshes:
-        assert m.faces.shape[0] > 1000 and np.all(_edges_ok(m.faces) == 2)
+        assert m.faces.shape[0] > (1000 if method == "mt" else 400) and np.all(_edges_ok(m.faces) == 2)
         assert m.vertices.shape[0] - 3 * m.faces.shape[0] // 2 + m.faces.shape[0] == 2
     one = mx.extract_mesh_from_code(lat[0])
     assert np.array_equal(one["vertices"], meshes[0].vertices) and one["faces"].dtype == np.int32
@@ -61,11 +83,13 @@ def test_mesh_extractor_drop_in():
     assert np.allclose(moved.vertices, meshes[0].vertices + np.array([0.1, 0.2, 0.5], dtype=np.float32), atol=1e-6)
 
 
-def test_surface_against_independent_marching_cubes_vertex_set():
-    """hm_extract_surface (marching tetrahedra) vs oracle/level_set.py on a DECODED grid: every vertex a marching-cubes
-    mesh of the reference would have (the linear-interpolation crossings of the grid's axis-aligned edges,
-    wild_completion/utils.py:573-586) is a vertex of our mesh, our remaining vertices lie on cell diagonals within one
-    cell of them, and the sampled surface is within a fraction of the cell size of the crossing cloud."""
+@pytest.mark.parametrize("method", ["mc", "mt"])
+def test_surface_against_independent_marching_cubes_vertex_set(method):
+    """hm_extract_surface_mc / hm_extract_surface vs oracle/level_set.py on a DECODED grid.  The vertices a marching-cubes
+    mesh of the reference has are the linear-interpolation crossings of the grid's axis-aligned edges
+    (wild_completion/utils.py:573-586).  Marching cubes: our vertex set IS that set (same count, matched one to one to
+    fp32 rounding).  Marching tetrahedra: it contains that set, the remaining vertices lie on cell diagonals within one
+    cell of it.  Either way the sampled surface is within a fraction of the cell size of the crossing cloud."""
     from hortimapping_amd import synthetic as S
     from hortimapping_amd.decoder import DecoderWeights
     from hortimapping_amd.mesher import MeshExtractor
@@ -74,7 +98,7 @@ def test_surface_against_independent_marching_cubes_vertex_set():
     p = S.make_synthetic_decoder(32, seed=1, r0=0.04, aniso=(1.0, 0.75, 1.3))
     dec = DecoderWeights.from_params(p)
     R, n = 0.08, 40
-    mx = MeshExtractor(dec, code_len=32, voxels_dim=n, cube_radius=R)
+    mx = MeshExtractor(dec, code_len=32, voxels_dim=n, cube_radius=R, method=method)
     lat = 0.05 * torch.randn(2, 32, generator=torch.Generator().manual_seed(3))
     grids = mx.decode_grids(lat).cpu().numpy()
     meshes = mx.extract_meshes(lat)
@@ -85,6 +109,9 @@ def test_surface_against_independent_marching_cubes_vertex_set():
         d = cKDTree(m.vertices.astype(np.float64)).query(cr)[0]
         assert d.max() < 1e-6                                            # the MC vertex set is contained, to fp32 rounding
         d2 = cKDTree(cr).query(m.vertices.astype(np.float64))[0]
-        assert d2.max() < 1.8 * h                                        # extra (diagonal) vertices stay within a cell
+        if method == "mc":
+            assert m.vertices.shape[0] == cr.shape[0] and d2.max() < 1e-6  # exactly the marching-cubes vertex set
+        else:
+            assert d2.max() < 1.8 * h                                    # extra (diagonal) vertices stay within a cell
         (m_mean, m_max), (c_mean, c_max) = LS.chamfer_to_crossings(m.sample_points_uniformly(20000, seed=1), cr)
         assert m_mean < 0.5 * h and m_max < 1.5 * h and c_mean < 0.25 * h        # 20000 samples: spacing ~ h / 4
