@@ -112,3 +112,22 @@ def test_depth_filters_of_the_challenge_loader():
         assert abs(f[y, x] - num / den) < 1e-6
     c = np.full((9, 9), 0.42, np.float32)
     assert np.allclose(_bilateral_3(c), c, atol=1e-7) and np.array_equal(_erode_11(c), c)
+
+
+def test_voxel_down_sample_equals_rowwise_formulation():
+    """Open3D-style voxel down-sampling of the Background submap (test_wild_completion.py:149-150): one point per occupied
+    voxel = mean of its points, voxels in (ix, iy, iz) order, grid anchored at min_bound - voxel / 2.  The fast
+    formulation (linear keys + bincount) gives the same bits as the plain one (np.unique over index rows + np.add.at)."""
+    from hortimapping_amd.data_prep import voxel_down_sample
+    rs = np.random.RandomState(4)
+    pts = np.concatenate([rs.uniform(-0.3, 0.4, (20000, 3)), rs.uniform(-0.3, -0.29, (500, 3))])
+    vs = 0.02
+    origin = pts.min(axis=0) - 0.5 * vs
+    idx = np.floor((pts - origin) / vs).astype(np.int64)
+    _, inv, cnt = np.unique(idx, axis=0, return_inverse=True, return_counts=True)
+    ref = np.zeros((len(cnt), 3))
+    np.add.at(ref, inv.reshape(-1), pts)
+    ref /= cnt[:, None]
+    out = voxel_down_sample(pts, vs)
+    assert out.shape == ref.shape and np.array_equal(out, ref) and cnt.max() > 3
+    assert voxel_down_sample(np.zeros((0, 3)), vs).shape == (0, 3)
