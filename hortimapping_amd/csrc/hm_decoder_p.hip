@@ -7,8 +7,10 @@
 //
 // What the single plane buys: the activations of 128 queries fit the LDS (one fp16 plane [k/8][q][8] = 128 KiB, the
 // f16x3 kernel needs 128 KiB for 64), so every weight byte fetched from L2 serves 128 queries instead of 64 and only
-// the hi plane (half the bytes) is fetched at all: the L2->VGPR weight stream that co-limits hm_decoder_h.hip drops
-// from 42.7 to 16 B/clk/CU and the kernel is bound by the matrix pipe alone.  Tiling: 512 threads, wave w owns the
+// the hi plane (half the bytes) is fetched at all: a quarter of the weight stream per query.  At the matrix rate of
+// its single pass the stream would still have to run at 32 B/clk/CU, and the measured K phase of a 512 x 512 stage is
+// ~26 k clocks against 16.4 k of MFMA (DESIGN.md section 8 has the trace and the micro-benchmarks): 0.31-0.33 of the
+// fp16 peak.  Tiling: 512 threads, wave w owns the
 // 32-row blocks {w, w+8} x four 32-query blocks (8 accumulators of 32x32 = 128 registers, plus 32 for the ReLU masks of
 // the 8 layers); A operands stream L2 -> VGPR two K-steps ahead (ring of three), B operands are refilled in place
 // from LDS right after their last use (one set), 8 MFMAs per K-step.
