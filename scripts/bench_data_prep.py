@@ -50,6 +50,25 @@ assert all(a["count"] == b["count"] and all(torch.equal(x, y) for x, y in zip(a[
 print(f"get_render_data, {NI} instances x {F} frames of {H}x{W}: host {t_h * 1e3 / NI:8.1f} ms / instance   device "
       f"{t_d * 1e3 / NI:6.2f} ms / instance (+ {t_up * 1e3:.0f} ms once to upload the sequence)   x{t_h / t_d:.0f}")
 
+# the one full pass over the sequence (hm_prep_stats): HBM-bound, id + depth images read once
+import ctypes
+lib = DP._prep_lib()
+lut = torch.full((NI + 3,), -1, dtype=torch.int32)
+lut[2:NI + 2] = torch.arange(NI, dtype=torch.int32)
+d_lut = lut.cuda()
+d_stats = torch.tensor([0, 2 ** 31 - 1, -1, 2 ** 31 - 1, -1], dtype=torch.int32).repeat(NI * F).cuda()
+st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+for rep in range(3):
+    e0.record()
+    lib.hm_prep_stats(frames.ids.data_ptr(), frames.depth.data_ptr(), F, H, W, d_lut.data_ptr(), NI + 3, NI, d_stats.data_ptr(), st)
+    e1.record()
+    torch.cuda.synchronize()
+ms = e0.elapsed_time(e1)
+nbytes = F * H * W * 8
+print(f"hm_prep_stats: {nbytes / 1e6:.0f} MB of id + depth images in {ms:.3f} ms = {nbytes / ms / 1e6:.0f} GB/s "
+      f"({nbytes / ms / 1e6 / 8000 * 100:.0f} % of the 8 TB/s HBM peak)")
+
 clouds = []
 for k in range(NI):
     d = rs.randn(6000, 3)
