@@ -366,14 +366,16 @@ __global__ __launch_bounds__(512, 2) void k_decoder(const DecodeArgs a) {
 __global__ void k_latent_bias(const DecoderDev dec, const float* __restrict__ latent, int ld_latent,
                               const int* __restrict__ active, float* __restrict__ c0,
                               float* __restrict__ c4) {
+  // grid (B, 4), 256 threads: quarter q of an instance's 2 x 512 outputs per workgroup -- the kernel is bound by each
+  // CU's L2 -> VGPR rate on the 1 MB of transposed weights, so it wants all 256 CUs, not one per instance
   __shared__ float z[MAX_L];
   const int b = blockIdx.x;
   if (active != nullptr && active[b] == 0) return;
   const int L = dec.L;
   for (int i = threadIdx.x; i < L; i += blockDim.x) z[i] = latent[(size_t)b * ld_latent + i];
   __syncthreads();
-  const int f = threadIdx.x & (HID - 1);
-  const bool second = threadIdx.x >= HID;
+  const int f = (blockIdx.y & 1) * 256 + threadIdx.x;
+  const bool second = blockIdx.y >= 2;
   const float* wT = second ? dec.w4z : dec.w0z;   // stored transposed [L][512] for coalescing
   // one serial fma chain per output (the summation order is part of the bitwise contract); what costs time is the
   // latency of the 256 dependent-looking loads, so fetch 32 weights ahead of the chain that consumes them
@@ -395,7 +397,7 @@ namespace hm {
 
 int launch_latent_bias(const hm_decoder_s* dec, const float* d_latent, int ld_latent, const int* d_active,
                        int B, float* d_c0, float* d_c4, hipStream_t stream) {
-  hipLaunchKernelGGL(k_latent_bias, dim3(B), dim3(2 * HID), 0, stream, dec->dev, d_latent, ld_latent,
+  hipLaunchKernelGGL(k_latent_bias, dim3(B, 4), dim3(256), 0, stream, dec->dev, d_latent, ld_latent,
                      d_active, d_c0, d_c4);
   HM_CHECK_HIP(hipGetLastError());
   return 0;
