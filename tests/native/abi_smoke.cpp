@@ -130,6 +130,42 @@ int main() {
     HM(hm_workspace_destroy(ws));
   }
   HM(hm_decoder_destroy(dec));
+  {
+    // data-preparation entry points: box crop of a point cloud (get_pose_init) and DBSCAN of two well-separated blobs
+    const int n = 1000;
+    std::vector<double> pts((size_t)n * 3);
+    for (int i = 0; i < n; ++i) { pts[3 * i] = 0.001 * i; pts[3 * i + 1] = 0.5; pts[3 * i + 2] = (i % 2) ? 0.1 : 0.9; }
+    const double box[6] = {0.1995, 0.0, 0.0, 0.3005, 1.0, 0.5};           // x in [0.2, 0.3], z = 0.1 only: odd i of 200..300
+    double *d_pts, *d_box; int *d_cnt, *d_idx; long long* d_off;
+    if (hipMalloc(&d_pts, pts.size() * 8) != hipSuccess || hipMalloc(&d_box, 48) != hipSuccess || hipMalloc(&d_cnt, 4) != hipSuccess ||
+        hipMalloc(&d_idx, n * 4) != hipSuccess || hipMalloc(&d_off, 8) != hipSuccess) return 4;
+    const long long zero = 0;
+    if (hipMemcpy(d_pts, pts.data(), pts.size() * 8, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(d_box, box, 48, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(d_off, &zero, 8, hipMemcpyHostToDevice) != hipSuccess) return 4;
+    HM(hm_prep_box_select(d_pts, n, d_box, 1, 0, d_cnt, d_off, d_idx, nullptr));
+    int cnt = -1;
+    if (hipMemcpy(&cnt, d_cnt, 4, hipMemcpyDeviceToHost) != hipSuccess) return 4;
+    HM(hm_prep_box_select(d_pts, n, d_box, 1, 1, d_cnt, d_off, d_idx, nullptr));
+    std::vector<int> idx(n, -1);
+    if (hipMemcpy(idx.data(), d_idx, (size_t)cnt * 4, hipMemcpyDeviceToHost) != hipSuccess) return 4;
+    if (cnt != 50 || idx[0] != 201 || idx[49] != 299) { printf("box select: %d %d %d\n", cnt, idx[0], idx[49]); return 5; }
+    std::vector<double> blobs((size_t)64 * 3);
+    for (int i = 0; i < 64; ++i) { blobs[3 * i] = (i < 40 ? 0.0 : 1.0) + 0.001 * (i % 8); blobs[3 * i + 1] = 0.001 * (i / 8); blobs[3 * i + 2] = 0.0; }
+    double* d_b; int *d_n, *d_mp, *d_comp;
+    const int nb = 64, mp = 3;
+    if (hipMalloc(&d_b, blobs.size() * 8) != hipSuccess || hipMalloc(&d_n, 4) != hipSuccess || hipMalloc(&d_mp, 4) != hipSuccess ||
+        hipMalloc(&d_comp, 64 * 4) != hipSuccess) return 4;
+    if (hipMemcpy(d_b, blobs.data(), blobs.size() * 8, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(d_n, &nb, 4, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(d_mp, &mp, 4, hipMemcpyHostToDevice) != hipSuccess) return 4;
+    HM(hm_prep_dbscan(d_b, d_n, 64, 1, 0.01, d_mp, d_comp, nullptr));
+    std::vector<int> comp(64);
+    if (hipMemcpy(comp.data(), d_comp, 64 * 4, hipMemcpyDeviceToHost) != hipSuccess) return 4;
+    for (int i = 0; i < 64; ++i)
+      if (comp[i] != (i < 40 ? 0 : 40)) { printf("dbscan: point %d in cluster %d\n", i, comp[i]); return 5; }
+    (void)hipFree(d_pts); (void)hipFree(d_box); (void)hipFree(d_cnt); (void)hipFree(d_idx); (void)hipFree(d_off);
+    (void)hipFree(d_b); (void)hipFree(d_n); (void)hipFree(d_mp); (void)hipFree(d_comp);
+  }
   printf("ABI_SMOKE_OK\n");
   return 0;
 }
