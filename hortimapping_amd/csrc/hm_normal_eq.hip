@@ -27,13 +27,15 @@ struct NormalEqArgs {
   float* Hext;     // [B][ldJ][ldJ], lower block pairs written
 };
 
-constexpr int CH = 64;        // rows staged per chunk
+constexpr int CH = 32;        // rows staged per chunk
 constexpr int TW = 64;        // tile width: 2 x 2 blocks of 32 columns per workgroup (one block per wave)
 
 // One workgroup (4 waves) owns a 64 x 64 tile = 2 x 2 lower-triangular 32x32 blocks of one instance's H and walks
-// all rows of up to three row segments in chunks of 64 rows: the chunk's two 64-column strips (A side, B side) and the
-// per-row weights are staged in LDS by coalesced 16-byte loads (double buffered: the next chunk is in flight while the
-// current one feeds 32 MFMAs per wave), so every J element is fetched once per tile instead of once per block pair.
+// all rows of up to three row segments in chunks of CH rows: the chunk's two 64-column strips (A side, B side) go
+// straight from global memory into LDS (global_load_lds_dwordx4, double buffered: the next chunk is in flight while the
+// current one feeds CH / 2 MFMAs per wave), so every J element is fetched once per tile instead of once per block pair.
+// Measured (rocprofv3, C2-joint): register-staged 64-row chunks 106 us, LDS-DMA 64 rows 98 us, 32 rows (four
+// workgroups per CU) 91 us, 16 rows 94 us.
 __global__ __launch_bounds__(256) void k_normal_eq(const NormalEqArgs a) {
   __shared__ float as[2][CH][TW];
   __shared__ float bs[2][CH][TW];
@@ -74,33 +76,38 @@ __global__ __launch_bounds__(256) void k_normal_eq(const NormalEqArgs a) {
     const float scale = sg.weight / (float)nd;
     const float* base = sg.rows + (size_t)b * sg.inst_stride + (size_t)sg.row_offset * a.ldJ;
     const int nchunk = (n + CH - 1) / CH;
-    f32x4 st[8];
     float sres = 0.f;
-    auto fetch = [&](int ch) {                 // global -> registers (issued one chunk ahead)
+    // staging by LDS-DMA (global_load_lds_dwordx4: no register hop, no ds_write): one wave instruction moves 4 rows x 64
+    // columns of a strip (lane l: row l / 16, 16-byte column chunk l % 16; LDS side linear = the row-major strip).
+    // Wave wv issues CH / 8 of the chunk's CH / 2 instructions (CH / 4 per strip).  Rows past the segment end and
+    // columns past the matrix are clamped to valid addresses: their weight is 0 / their H entries are never stored.
+    auto dma = [&](int buf, int ch) {
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const int row = ch * CH + srow + 8 * k;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (row < n && scol < a.ldJ) v = *reinterpret_cast<const f32x4*>(base + (size_t)row * a.ldJ + scol);
-        st[k] = v;
+      for (int k = 0; k < CH / 8; ++k) {
+        const int i = (CH / 8) * wv + k;                  // instruction of the chunk
+        const bool sB = i >= CH / 4;
+        const int r = 4 * (i % (CH / 4)) + (lane >> 4);   // row within the chunk
+        int row = ch * CH + r;
+        row = row < n ? row : n - 1;
+        int col = (sB ? tj : ti) * TW + (lane & 15) * 4;
+        col = col + 4 <= a.ldJ ? col : a.ldJ - 4;
+        const float* src = base + (size_t)row * a.ldJ + col;
+        float* dst = sB ? &bs[buf][4 * (i % (CH / 4))][0] : &as[buf][4 * (i % (CH / 4))][0];
+        __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)src,
+                                         (void __attribute__((address_space(3)))*)dst, 16, 0, 0);
       }
-      if (tid < CH) { const int row = ch * CH + tid; sres = row < n ? base[(size_t)row * a.ldJ + rcol] : 0.f; }
     };
-    auto stash = [&](int buf, int ch) {        // registers -> LDS
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        float* dst = sideB ? &bs[buf][srow + 8 * k][(sch & 15) * 4] : &as[buf][srow + 8 * k][(sch & 15) * 4];
-        *reinterpret_cast<f32x4*>(dst) = st[k];
-      }
-      if (tid < CH) cw[buf][tid] = (ch * CH + tid < n) ? scale * huber_rho(sres, sg.robust_th) : 0.f;
-    };
-    fetch(0);
+    auto fetch_w = [&](int ch) { if (tid < CH) { const int row = ch * CH + tid; sres = row < n ? base[(size_t)row * a.ldJ + rcol] : 0.f; } };
+    auto stash_w = [&](int buf, int ch) { if (tid < CH) cw[buf][tid] = (ch * CH + tid < n) ? scale * huber_rho(sres, sg.robust_th) : 0.f; };
     __syncthreads();                           // previous segment's readers are done with both buffers
-    stash(0, 0);
+    dma(0, 0);
+    fetch_w(0);
+    stash_w(0, 0);
     for (int ch = 0; ch < nchunk; ++ch) {
       const int buf = ch & 1;
-      if (ch + 1 < nchunk) fetch(ch + 1);
+      __builtin_amdgcn_s_waitcnt(0x0070);      // this wave's DMA of chunk `ch` (and its weight loads) have landed
       __syncthreads();                         // chunk `ch` visible in LDS; buffer buf^1 free
+      if (ch + 1 < nchunk) { dma(buf ^ 1, ch + 1); fetch_w(ch + 1); }
       if (work) {
 #pragma unroll
         for (int g = 0; g < CH / 8; ++g) {
@@ -113,7 +120,7 @@ __global__ __launch_bounds__(256) void k_normal_eq(const NormalEqArgs a) {
           }
         }
       }
-      if (ch + 1 < nchunk) stash(buf ^ 1, ch + 1);
+      if (ch + 1 < nchunk) stash_w(buf ^ 1, ch + 1);
     }
   }
   if (work) {
