@@ -9,6 +9,7 @@ Prints ONE JSON line (rank 0) with the `roofline` and `cpu_baseline` objects.
     python bench.py                       # 1 GPU, 64 peppers (weak scaling: 64 per GPU)
     python bench.py --total 4096          # strong scaling (configs[3]): 4096 instances sharded over the GPUs, each rank
                                           # running its shard in chunks of --batch (default 256 in this mode)
+    python bench.py --gpus N              # no launcher: spawns its N ranks itself (torch.distributed.run, RCCL)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -47,7 +48,16 @@ PRECISIONS = {
             "f16 = plain fp16 MFMA decoder (BASELINE.json configs[4]): one pass per product, fp16 activations, 128-query "
             "tiles; fp16-class results (~1e-3), not the reference's fp32; never the default line"),
 }
-TRAFFIC_FILE = os.path.join("profiles", "r02_traffic.json")
+
+
+def traffic_file():
+    """Newest committed profiles/rNN_traffic.json (regenerated from the PMC passes by scripts/collect_profiles.sh)."""
+    import glob
+    fs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_traffic.json")))
+    return os.path.relpath(fs[-1], ROOT) if fs else None
+
+
+TRAFFIC_FILE = traffic_file()
 
 
 def plan_shard(rank, world, per_gpu, total, chunk):
@@ -162,8 +172,32 @@ def load_trained_decoder():
         return {k: (int(f[k]) if k in ("latent_dim", "hidden") else f[k]) for k in f.files}
 
 
+def launched_bare():
+    """True when this process was started as plain `python bench.py ...` (no torchrun / no rank environment)."""
+    return not any(k in os.environ for k in ("RANK", "LOCAL_RANK", "TORCHELASTIC_RUN_ID")) and \
+        int(os.environ.get("WORLD_SIZE", "1")) == 1
+
+
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves, exactly the way the driver's command
+    does (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P
+    bench.py ...`, one process per GPU), pass rank 0's JSON line through and return the launcher's exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL across processes needs it on this driver
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    return subprocess.call(cmd, env=env)
+
+
 def main(argv=None, emit=True):
     args = parse_args(argv)
+    if args.gpus > 1 and launched_bare():
+        raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:] if argv is None else argv))
     from hortimapping_amd import distributed as D
     import torch.distributed as dist
     stub = args.stub_cpu
@@ -174,7 +208,8 @@ def main(argv=None, emit=True):
     if args.gpus != world:
         if world > 1 or args.gpus > 1:
             raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run "
-                             f"--nproc-per-node {args.gpus}")
+                             f"--nproc-per-node {args.gpus} (or start `python bench.py --gpus {args.gpus}` without any "
+                             "RANK / WORLD_SIZE in the environment: it then spawns its ranks itself)")
     if not stub:
         if not torch.cuda.is_available():
             raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
@@ -205,6 +240,7 @@ def main(argv=None, emit=True):
             return D.pack_records(lat, T, torch.full((hi - lo,), args.iters), torch.full((hi - lo,), 8))
         profile_read = lambda: (0.0, 0)
         profile_on = lambda on: None
+        count_step = lambda: [0] * 5
         n_s = 0
     else:
         from hortimapping_amd import _lib, synthetic as S, workloads as W, optimizer as HO
@@ -241,6 +277,18 @@ def main(argv=None, emit=True):
 
         def profile_on(on):
             lib.hm_workspace_profile(ws.handle, 1 if on else 0)
+
+        lib.hm_workspace_counters.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        lib.hm_workspace_counters_read.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_longlong), ctypes.c_void_p]
+
+        def count_step():
+            """One extra UNTIMED step with the device-side work counters on (N_J, N_F, V per iteration)."""
+            lib.hm_workspace_counters(ws.handle, 1)
+            step()
+            out5 = (ctypes.c_longlong * 5)()
+            lib.hm_workspace_counters_read(ws.handle, out5, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+            lib.hm_workspace_counters(ws.handle, 0)
+            return [int(v) for v in out5]
 
         def profile_read():
             ms_tot, n_launch = ctypes.c_double(0), ctypes.c_longlong(0)
@@ -290,15 +338,21 @@ def main(argv=None, emit=True):
         flops = q * FLOP_FWD_BWD
         achieved = flops / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
         traffic, tsrc, busy = None, None, None    # HBM/fabric bytes per launch: from committed PMC passes of the same workload
-        tj = os.path.join(ROOT, TRAFFIC_FILE)
-        if kind == "joint" and not strong and per_gpu == 64 and L == 256 and args.decoder == "analytic" and os.path.exists(tj):
+        tj = os.path.join(ROOT, TRAFFIC_FILE) if TRAFFIC_FILE else None
+        if kind == "joint" and not strong and per_gpu == 64 and L == 256 and args.decoder == "analytic" and tj and os.path.exists(tj):
             tj_ = json.load(open(tj)).get(precision, {})
             traffic, busy = tj_.get("bytes_per_launch"), tj_.get("mfma_pipe_busy_frac")
             if traffic is not None:
                 tsrc = f"{TRAFFIC_FILE} (rocprofv3 PMC passes of the same workload, committed; NOT measured in this run)"
+        # algorithmic bytes of one launch: per query 16 B in (float4 point), 4 B sdf + one (L+8)-float Jacobian row out; the
+        # weight operands the kernel touches once (7 x 512^2 products each way; 4 B per weight in every arithmetic: fp32, or
+        # fp16 hi + lo) -- what an ideal kernel with every tile sharing one weight fetch would move
+        alg_bytes = int(q * (16 + 4 + (L + 8) * 4) + 2 * 7 * 512 * 512 * 4)
         r = {"bound": "mfma", "kernel": kname + " (SDF-term decoder forward + input-gradient backward)",
              "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
-             "traffic": traffic, "traffic_source": tsrc, "launches": n_launch, "avg_launch_ms": round(avg_ms, 4),
+             "traffic": traffic, "traffic_source": tsrc, "algorithmic_bytes_per_launch": alg_bytes,
+             "traffic_over_algorithmic": (round(traffic / alg_bytes, 2) if traffic else None),
+             "launches": n_launch, "avg_launch_ms": round(avg_ms, 4),
              "algorithmic_flop_per_launch": int(flops)}
         if busy is not None:                      # matrix-pipe utilisation (all MFMA issued, incl. the 3 passes of f16x3)
             r["mfma_pipe_busy_frac"] = busy
@@ -310,7 +364,29 @@ def main(argv=None, emit=True):
             r["note"] = "3 MFMA passes per forward product, 1 per backward product: ceiling 1/2 of the fp16 peak"
         return r
 
+    def step_roofline(precision, ms_step, cnt):
+        """Whole-iteration algorithmic flop:  A = N_J (F_f + F_b) + N_F F_f + sum_terms 2 n_t E^2 + 2/3 E^3
+        per instance-iteration, summed over the step with the DEVICE-SIDE counters of an extra untimed step (the counts
+        are data, not timing: the same inputs give the same counts in every step)."""
+        n_ii, n_s_q, n_f, n_g, n_v = cnt
+        E = L + (0 if shape_only else 7)
+        a_dec = (n_s_q + n_g) * FLOP_FWD_BWD + n_f * FLOP_FWD
+        a_syrk = 2 * (n_s_q + 2 * n_v) * E * E
+        a_solve = n_ii * (2.0 / 3.0) * E ** 3
+        A = a_dec + a_syrk + a_solve
+        peak = PRECISIONS[precision][0]
+        ach = A / (ms_step * 1e-3) / 1e12 if ms_step > 0 else 0.0
+        return {"algorithmic_flop_per_step": int(A), "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
+                "frac": round(ach / peak, 4), "ms_per_step": round(ms_step, 3),
+                "counts_per_step": {"instance_iterations": n_ii, "N_J_sdf_term": n_s_q, "N_J_render": n_g,
+                                    "N_F_ray_samples": n_f, "V_rays": n_v},
+                "split_flop": {"decoder": int(a_dec), "normal_equations": int(a_syrk), "solve": int(a_solve)},
+                "formula": "A = N_J*(F_f+F_b) + N_F*F_f + sum_terms 2*n_t*E^2 + (2/3)*E^3 per instance-iteration "
+                           "(F_f = F_b = 3,671,040; E = L + 7 joint / L shape-only; terms: N_s, V, V rows); counts from the "
+                           "device-side counters of hm_workspace_counters in one extra untimed step"}
+
     dt, ms_tot, n_launch, allrec = measure(args.precision, args.steps, args.warmup)
+    counts = count_step() if not stub else None
 
     if rank == 0:
         if args.dump_records:
@@ -337,6 +413,8 @@ def main(argv=None, emit=True):
             "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": args.precision, "dtype_note": PRECISIONS[args.precision][2],
             "data": "synthetic",
+            "rccl_ranks": (dist.get_world_size() if dist.is_initialized() else 1),
+            "collective_backend": (dist.get_backend() if dist.is_initialized() else "none (single process)"),
             "config": {
                 "workload": head + ", " + (joint_txt if kind == "joint" else sdf_txt),
                 "instances_total": n_total, "instances_per_gpu": n_local, "chunk": chunk if strong else per_gpu,
@@ -353,6 +431,7 @@ def main(argv=None, emit=True):
             out["stub"] = "rank logic only (gloo, CPU stand-in for the GPU optimisation): NOT a measurement"
         else:
             out["roofline"] = roofline(args.precision, ms_tot, n_launch)
+            out["roofline"]["step"] = step_roofline(args.precision, dt / args.steps * 1e3, counts)
     if not stub and not args.no_exact and world == 1 and not strong:
         # the same job in the other decoder arithmetics, one timed step each, for reference next to the primary line
         for other, key in (("f32", "exact_f32"), ("f16x3f_f16b", "mixed_f16x3f_f16b"), ("f16", "plain_f16")):
@@ -384,6 +463,20 @@ def main(argv=None, emit=True):
         out["batch_256"] = {"value": o3["value"], "unit": o3["unit"], "steps": 1, "dtype": o3["dtype"],
                             "ms_per_step": o3["ms_per_step"], "instances_per_gpu": 256,
                             "note": "64 distinct synthetic peppers replicated cyclically; not the BASELINE configuration"}
+        # SURVEY.md 8d "run twice": C2-sdf = the shape-only loop (shape_opt_deepsdf) on 2048 surface points per instance
+        o4 = main(["--steps", "1", "--warmup", "1", "--iters", str(args.iters), "--workload", "c2_sdf", "--precision",
+                   args.precision, "--no-exact", "--no-cpu-baseline"], emit=False)
+        out["c2_sdf"] = {"value": o4["value"], "unit": o4["unit"], "steps": 1, "dtype": o4["dtype"],
+                         "ms_per_step": o4["ms_per_step"], "workload": o4["config"]["workload"], "roofline": o4["roofline"]}
+        # BASELINE.json configs[3] as ONE rank of eight sees it: 512 of the 4096 instances, two chunks of 256 through one
+        # workspace (the strong-scaling job is `bench.py --gpus 8 --total 4096`)
+        o5 = main(["--steps", "1", "--warmup", "1", "--iters", str(args.iters), "--total", "512", "--batch", "256",
+                   "--precision", args.precision, "--no-exact", "--no-cpu-baseline"], emit=False)
+        out["configs3_rank_share"] = {"value": o5["value"], "unit": o5["unit"], "steps": 1, "dtype": o5["dtype"],
+                                      "ms_per_step": o5["ms_per_step"], "instances": 512, "chunk": 256,
+                                      "roofline_step": o5["roofline"]["step"],
+                                      "note": "one rank's share of `--gpus 8 --total 4096` (64 distinct synthetic peppers "
+                                              "replicated cyclically), run on this one GPU"}
     if rank == 0:
         if not stub and not args.no_cpu_baseline and world == 1:   # N = 1 only; other ranks would idle in the barrier
             out["cpu_baseline"] = cpu_baseline(params, cfg, dicts[0], kind)

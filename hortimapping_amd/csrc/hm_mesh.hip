@@ -10,6 +10,8 @@
 // vertices are evaluated from the lower to the higher grid index so that shared vertices are bit-identical and the
 // host can weld them with an exact `unique`.  Two passes (count, scan, emit) keep the triangle order deterministic.
 // HBM-bound integer/byte work: one thread per cell, coalesced along z.
+#include <mutex>
+
 #include "hm_common.h"
 #include "hm_internal.h"
 
@@ -302,17 +304,27 @@ static int build_mc_table(unsigned char (&ntri)[256], unsigned char (&tri)[256][
   return worst;
 }
 
+// The table is built once per process (host side); the __constant__ copies are PER DEVICE, so the upload is tracked
+// per device index (hipMemcpyToSymbol writes the current device only) under a mutex.
 static int upload_mc_table() {
-  static int state = 0;                         // 0: not yet, 1: done, -1: failed
-  if (state != 0) return state;
+  static std::mutex mu;
+  static int built = 0;                         // 0: not yet, 1: done, -1: failed
   static unsigned char ntri[256];
   static unsigned char tri[256][MC_MAXT * 3];
-  for (auto& row : tri) for (auto& v : row) v = 0;
-  if (build_mc_table(ntri, tri) < 0) { state = -1; return state; }
+  static bool uploaded[64] = {};
+  std::lock_guard<std::mutex> lock(mu);
+  if (built == 0) {
+    for (auto& row : tri) for (auto& v : row) v = 0;
+    built = build_mc_table(ntri, tri) < 0 ? -1 : 1;
+  }
+  if (built != 1) return -1;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return -1;
+  if (uploaded[dev]) return 1;
   if (hipMemcpyToSymbol(HIP_SYMBOL(c_mc_ntri), ntri, sizeof(ntri)) != hipSuccess ||
-      hipMemcpyToSymbol(HIP_SYMBOL(c_mc_tri), tri, sizeof(tri)) != hipSuccess) { state = -1; return state; }
-  state = 1;
-  return state;
+      hipMemcpyToSymbol(HIP_SYMBOL(c_mc_tri), tri, sizeof(tri)) != hipSuccess) return -1;
+  uploaded[dev] = true;
+  return 1;
 }
 
 template <bool MC>

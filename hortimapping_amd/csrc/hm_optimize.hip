@@ -44,7 +44,13 @@ struct hm_workspace_s {
   int* h_act_count;               // [N_ACT], pinned
   hipEvent_t ev_act[N_ACT];
   bool act_ready;
+  // optional work counters (measurement): sums over every instance-iteration since the last enable
+  int count_on;
+  unsigned long long* d_counters; // [N_COUNTER]
 };
+
+// hm_workspace_counters_read layout
+enum { CNT_INST_ITER = 0, CNT_SDF_QUERIES, CNT_RAY_FWD, CNT_RAY_JAC, CNT_RAYS, N_COUNTER = 8 };
 
 namespace {
 
@@ -66,6 +72,7 @@ void carve(hm_workspace_s* w, Carver& c) {
   const int B = w->lim.max_batch, F = w->lim.max_frames, R = w->lim.max_rays;
   const size_t nray = (size_t)F * R;
   w->d_act_count = c.take<int>(hm_workspace_s::N_ACT);
+  w->d_counters = c.take<unsigned long long>(N_COUNTER);
   w->c0 = c.take<float>((size_t)B * HID);
   w->c4 = c.take<float>((size_t)B * HID);
   w->ptsS = c.take<float>((size_t)B * w->nS_stride * 4);
@@ -153,6 +160,35 @@ __global__ void k_collect_counts(const RenderCfg cfg, const RenderBuffers rb, in
   out[b * 4 + 3] = 0;
 }
 
+// Work done by ONE iteration, summed over the instances that are active in it (one block; launched before the solve
+// kernel updates the flags): instance-iterations, SDF-term Jacobian queries, forward-only ray samples (ball-valid
+// samples of the frames that count, loss.py:38-49), ray samples that need the Jacobian, emitted rays.
+__global__ void k_accumulate_counts(const RenderCfg cfg, const RenderBuffers rb, int B, int mode,
+                                    const int* __restrict__ n_points, const int* __restrict__ active,
+                                    unsigned long long* __restrict__ acc) {
+  __shared__ unsigned long long s[4][5];
+  unsigned long long c[5] = {0, 0, 0, 0, 0};
+  for (int b = threadIdx.x; b < B; b += blockDim.x) {
+    if (active[b] == 0) continue;
+    c[0] += 1;
+    c[1] += (unsigned long long)n_points[b];
+    if (mode == 0) {
+      for (int f = 0; f < cfg.F; ++f)
+        if (f < rb.n_frames[b] && rb.valid_count[b * cfg.F + f] >= cfg.min_valid) c[2] += rb.valid_count[b * cfg.F + f];
+      c[3] += (unsigned long long)rb.nG[b];
+      c[4] += (unsigned long long)rb.V[b];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c[k] += __shfl_xor(c[k], o);
+    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6][k] = c[k];
+  }
+  __syncthreads();
+  if (threadIdx.x < 5) acc[threadIdx.x] += s[0][threadIdx.x] + s[1][threadIdx.x] + s[2][threadIdx.x] + s[3][threadIdx.x];
+}
+
 int check_batch(const hm_workspace_s* ws, const hm_batch* bt, int mode) {
   if (bt == nullptr) { hm_set_error("null batch"); return -1; }
   if (bt->B <= 0 || bt->B > ws->lim.max_batch) { hm_set_error("batch size %d exceeds workspace limit %d", bt->B, ws->lim.max_batch); return -1; }
@@ -199,13 +235,18 @@ int render_pass(hm_workspace_s* ws, const RenderCfg& rc, const RenderBuffers& rb
 
 }  // namespace
 
+// test hook (tests of the Cholesky fallback of the solve kernel): 1 sends every system through the direct solve.
+// A debug entry point, not an environment variable read on the product path.
+static int g_force_direct = 0;
+extern "C" void hm_debug_force_direct_solve(int on) { g_force_direct = on ? 1 : 0; }
+
 extern "C" int hm_workspace_create(hm_decoder_s* dec, const hm_limits* lim, hm_workspace_s** out) {
   if (dec == nullptr || lim == nullptr || out == nullptr) { hm_set_error("null argument"); return -1; }
   if (lim->max_batch <= 0 || lim->max_points <= 0 || lim->max_frames < 0 || lim->max_rays < 0 ||
       lim->max_samples < 0 || lim->max_samples > 64 || lim->max_frames > 64) {
     hm_set_error("bad limits (need batch>0, points>0, frames<=64, samples<=64)"); return -1; }
   hm_workspace_s* w = new hm_workspace_s();
-  w->profile_on = 0; w->ev_used = 0; w->d_blob = nullptr; w->blob_bytes = 0;
+  w->profile_on = 0; w->ev_used = 0; w->d_blob = nullptr; w->blob_bytes = 0; w->count_on = 0;
   w->dec = dec; w->lim = *lim; w->L = dec->L; w->ldJ = dec->L + POSE_PAD;
   if (w->lim.max_frames == 0 || w->lim.max_rays == 0 || w->lim.max_samples == 0) {
     w->lim.max_frames = 1; w->lim.max_rays = 1; w->lim.max_samples = 2;     // shape-only workspace
@@ -228,12 +269,22 @@ extern "C" int hm_workspace_create(hm_decoder_s* dec, const hm_limits* lim, hm_w
   w->h_act_count = nullptr;
   w->act_ready = false;
   e = hipHostMalloc(reinterpret_cast<void**>(&w->h_act_count), hm_workspace_s::N_ACT * sizeof(int), hipHostMallocDefault);
+  int n_ev = 0;
   if (e == hipSuccess) {
     w->act_ready = true;
-    for (int i = 0; i < hm_workspace_s::N_ACT; ++i)
-      if (hipEventCreateWithFlags(&w->ev_act[i], hipEventDisableTiming) != hipSuccess) w->act_ready = false;
+    for (; n_ev < hm_workspace_s::N_ACT; ++n_ev)
+      if (hipEventCreateWithFlags(&w->ev_act[n_ev], hipEventDisableTiming) != hipSuccess) { w->act_ready = false; break; }
+  } else {
+    w->h_act_count = nullptr;
   }
-  if (!w->act_ready) { hm_set_error("pinned host memory / events for the early-stop poll unavailable"); (void)hipFree(w->d_blob); delete w; return -2; }
+  if (!w->act_ready) {
+    hm_set_error("pinned host memory / events for the early-stop poll unavailable");
+    for (int i = 0; i < n_ev; ++i) (void)hipEventDestroy(w->ev_act[i]);
+    if (w->h_act_count) (void)hipHostFree(w->h_act_count);
+    (void)hipFree(w->d_blob);
+    delete w;
+    return -2;
+  }
   *out = w;
   return 0;
 }
@@ -257,6 +308,21 @@ extern "C" int hm_workspace_profile_read(hm_workspace_s* w, double* ms_total, lo
   }
   *ms_total = tot;
   *launches = (long long)(w->ev_used / 2);
+  return 0;
+}
+
+// Work counters: enable (and zero) / disable, then read the sums after synchronising `stream`.
+extern "C" int hm_workspace_counters(hm_workspace_s* w, int enable) {
+  if (w == nullptr) { hm_set_error("null workspace"); return -1; }
+  w->count_on = enable;
+  if (enable) HM_CHECK_HIP(hipMemset(w->d_counters, 0, N_COUNTER * sizeof(unsigned long long)));
+  return 0;
+}
+
+extern "C" int hm_workspace_counters_read(hm_workspace_s* w, long long* out5, void* stream) {
+  if (w == nullptr || out5 == nullptr) { hm_set_error("null argument"); return -1; }
+  HM_CHECK_HIP(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+  HM_CHECK_HIP(hipMemcpy(out5, w->d_counters, 5 * sizeof(long long), hipMemcpyDeviceToHost));
   return 0;
 }
 
@@ -295,9 +361,7 @@ extern "C" int hm_optimize_batch(hm_workspace_s* ws, const hm_opt_cfg* cfg, cons
   RenderCfg rcfg = make_render_cfg(ws, cfg);
   RenderBuffers rb = ws->rb;
   if (mode == 0) { bind_inputs(rb, bt); rb.status = bt->d_status; }
-  // test hook: HM_FORCE_DIRECT_SOLVE=1 sends every system through the Cholesky fallback of the solve kernel
-  const char* fd = getenv("HM_FORCE_DIRECT_SOLVE");
-  const int force_direct = (fd != nullptr && fd[0] == '1') ? 1 : 0;
+  const int force_direct = g_force_direct;
 
   // Early stop of the LAUNCH loop.  Finished instances are frozen on the device (`active` flags), so results never depend
   // on this; but a batch whose instances have all converged by iteration 7 of max_iter 50 would still be sent 43 x 13
@@ -368,6 +432,9 @@ extern "C" int hm_optimize_batch(hm_workspace_s* ws, const hm_opt_cfg* cfg, cons
     sa.eps_g = cfg->epsilon_g; sa.eps_c = cfg->epsilon_c; sa.eps_t = cfg->epsilon_t; sa.eps_r = cfg->epsilon_r;
     sa.eps_s = cfg->epsilon_s;
     sa.force_direct = force_direct;
+    if (ws->count_on)
+      hipLaunchKernelGGL(k_accumulate_counts, dim3(1), dim3(256), 0, st, rcfg, rb, B, mode, bt->d_n_points, ws->active,
+                         ws->d_counters);
     if (dbg && dbg->d_counts && mode == 0)
       hipLaunchKernelGGL(k_collect_counts, dim3((B + 63) / 64), dim3(64), 0, st, rcfg, rb, B, dbg->d_counts);
     rc = launch_solve_update(sa, B, st);

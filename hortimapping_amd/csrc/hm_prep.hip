@@ -321,7 +321,9 @@ extern "C" int hm_prep_scan(const int* d_id_imgs, const float* d_depth, int H, i
   if (P == 0) return 0;
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (gather) {
-    const size_t sm = ((size_t)4 * cap + 8) * sizeof(int);
+    const size_t sm = ((size_t)4 * cap + 8) * sizeof(int);         // up to 128 KiB at cap 8192: beyond the 64 KiB default
+    HM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_prep_scan<true>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
     hipLaunchKernelGGL((k_prep_scan<true>), dim3(P), dim3(NTP), sm, st, d_id_imgs, d_depth, H, W, d_pairs, d_counts,
                        d_sel, d_perm, cap, d_invK, d_pix, d_depth_out, d_rays);
   } else {
@@ -339,12 +341,9 @@ extern "C" int hm_prep_dbscan(const double* d_pts, const int* d_n_pts, int n_str
     return -1;
   }
   if (B == 0) return 0;
-  static bool attr_set = false;
   const size_t sm = (size_t)3 * DB_MAXN * sizeof(double) + (size_t)DB_MAXN * sizeof(int);
-  if (!attr_set) {
-    HM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_dbscan), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
-    attr_set = true;
-  }
+  // function attributes are per device: set on every call (a host-side table write) rather than cached per process
+  HM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_dbscan), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
   hipLaunchKernelGGL(k_dbscan, dim3(B), dim3(DB_NT), sm, static_cast<hipStream_t>(stream), d_pts, d_n_pts, n_stride, eps,
                      d_min_pts, d_comp);
   HM_CHECK_HIP(hipGetLastError());

@@ -123,6 +123,8 @@ def get_render_data_device(submap_ids, frames: DeviceFrames, cam_poses, img_size
     # pass 1: mask statistics of every wanted instance in every frame
     lut = np.full(max(frames.max_id, max(int(s) for s in submap_ids)) + 1, -1, np.int32)
     for slot, sid in enumerate(submap_ids):
+        if int(sid) < 0:
+            raise ValueError(f"submap id {int(sid)} is negative (ids index the instance-id images)")
         assert lut[int(sid)] < 0, "duplicate instance id"
         lut[int(sid)] = slot
     d_lut = torch.from_numpy(lut).to(dev)
@@ -253,10 +255,23 @@ def dbscan_labels_device(clouds, eps, min_pts):
 
 
 def clean_pcd_device(clouds, cluster_dist_thre=0.01, outlier_point_ratio=0.02):
-    """`clean_pcd` (`utils.py:407-417`) for a list of clouds, DBSCAN on the GPU."""
-    min_pts = [max(1, int(c.shape[0] * outlier_point_ratio)) for c in clouds]
-    labels = dbscan_labels_device(clouds, cluster_dist_thre, min_pts)
-    return [_mode_cluster(c, l) for c, l in zip(clouds, labels)]
+    """`clean_pcd` (`utils.py:407-417`) for a list of clouds, DBSCAN on the GPU.  A cloud beyond the kernel's
+    DBSCAN_MAX_POINTS (its points and labels must fit one workgroup's LDS) takes the host `clean_pcd` instead -- same
+    labels, see `dbscan_labels_device` -- and an empty cloud stays empty, so a configuration with a large
+    `opt.recon.n_pts` keeps working."""
+    out = [None] * len(clouds)
+    on_dev = [i for i, c in enumerate(clouds) if 0 < c.shape[0] <= DBSCAN_MAX_POINTS]
+    for i, c in enumerate(clouds):
+        if c.shape[0] == 0:
+            out[i] = c
+        elif c.shape[0] > DBSCAN_MAX_POINTS:
+            out[i] = clean_pcd(c, cluster_dist_thre, outlier_point_ratio)
+    if on_dev:
+        sub = [clouds[i] for i in on_dev]
+        min_pts = [max(1, int(c.shape[0] * outlier_point_ratio)) for c in sub]
+        for i, c, l in zip(on_dev, sub, dbscan_labels_device(sub, cluster_dist_thre, min_pts)):
+            out[i] = _mode_cluster(c, l)
+    return out
 
 
 def clean_mesh(mesh, sample_point_count=5000, cluster_dist_thre=0.01, outlier_point_ratio=0.02, seed=0) -> np.ndarray:

@@ -2,8 +2,11 @@
 
 `MeshExtractor(decoder, code_len, voxels_dim, cube_radius)` keeps the reference's constructor and methods
 (`extract_mesh_from_code`, `complete_mesh`).  The voxels_dim^3 grid is decoded by the forward MFMA kernel
-(`hm_decode_batch`, batched over instances) and the zero level set is extracted on the GPU by `hm_extract_surface`
-(marching tetrahedra; scikit-image's marching cubes, used by the reference at utils.py:573-576, is not in the image).
+(`hm_decode_batch`, batched over instances) and the zero level set is extracted on the GPU by
+`hm_extract_surface_mc` -- marching CUBES, the default: its vertices are exactly the grid-edge crossings that the
+reference's scikit-image call (utils.py:573-576) produces; the triangulation of ambiguous cells comes from our own
+table and may differ from scikit-image's Lewiner tables (skimage is not in the image, so faces are unpinned) -- or,
+with `method="mt"`, by `hm_extract_surface` (marching tetrahedra, round 1: a finer triangulation of the same surface).
 Open3D is not available either, so `complete_mesh` returns a small `TriangleMesh` record instead of an
 `o3d.geometry.TriangleMesh`; `write_ply` writes the binary little-endian PLY layout of `write_mesh_to_ply`
 (utils.py:591-611: vertex x,y,z float32; face vertex_indices int32 list)."""

@@ -41,6 +41,49 @@ def completed_points_world(sdf_fn, T_ow: np.ndarray, n_dirs: int = 2000, r_max: 
     return p_o @ T_wo[:3, :3].T + T_wo[:3, 3]
 
 
+def level_set_points_batched(dec, latents, n_dirs: int = 2000, r_max: float = 0.08, n_bisect: int = 24) -> np.ndarray:
+    """(n, n_dirs, 3) object-frame zero-level-set points of n shapes at once: `sample_level_set` with the sdf evaluated
+    by the batched decoder forward on the GPU (`dec` should be in the exact-fp32 arithmetic so that ONE sampler serves
+    every party of a comparison)."""
+    from . import ops
+    lat = torch.as_tensor(np.asarray(latents), dtype=torch.float32).cuda().contiguous()
+    n = lat.shape[0]
+    dirs = torch.from_numpy(fibonacci_dirs(n_dirs)).float().cuda()
+    lo = torch.zeros(n, n_dirs, device="cuda")
+    hi = torch.full((n, n_dirs), float(r_max), device="cuda")
+    nq = torch.full((n,), n_dirs, dtype=torch.int32, device="cuda")
+    pts4 = torch.zeros(n, (n_dirs + 63) // 64 * 64, 4, device="cuda")
+    for _ in range(n_bisect):
+        mid = 0.5 * (lo + hi)
+        pts4[:, :n_dirs, :3] = dirs[None] * mid[..., None]
+        y, _ = ops.decode_batch(dec, lat, pts4, nq, mode=0)
+        inside = y[:, :n_dirs] < 0
+        lo = torch.where(inside, mid, lo)
+        hi = torch.where(inside, hi, mid)
+    return (dirs[None] * (0.5 * (lo + hi))[..., None]).double().cpu().numpy()
+
+
+def completion_metrics(dec, latents, T_ows, gt_points_world, T_wo_true, n_dirs: int = 2000) -> np.ndarray:
+    """(n, 4) per instance: Chamfer distance of the completed shape to the ground-truth shape [m] (both sampled by
+    `level_set_points_batched`, mapped to the world by T_wo = inverse(T_ow); metrics_3d/chamfer_distance.py:16-26),
+    translation error [m], rotation error [deg], scale ratio (`pose_error`)."""
+    P = level_set_points_batched(dec, latents, n_dirs)
+    out = np.zeros((len(P), 4))
+    for i in range(len(P)):
+        T_wo = np.linalg.inv(np.asarray(T_ows[i], dtype=np.float64))
+        pw = P[i] @ T_wo[:3, :3].T + T_wo[:3, 3]
+        out[i, 0] = chamfer_distance(pw, gt_points_world[i])
+        out[i, 1:] = pose_error(np.asarray(T_ows[i]), T_wo_true[i])
+    return out
+
+
+def ground_truth_points_world(dec, z_true, T_wo_true, n_dirs: int = 2000):
+    """World-frame level-set samples of the generating shapes (z_true, T_wo_true) of synthetic instances."""
+    P = level_set_points_batched(dec, z_true, n_dirs)
+    return [P[i] @ np.asarray(T_wo_true[i], dtype=np.float64)[:3, :3].T + np.asarray(T_wo_true[i], dtype=np.float64)[:3, 3]
+            for i in range(len(P))]
+
+
 def chamfer_distance(A: np.ndarray, B: np.ndarray) -> float:
     from scipy.spatial import cKDTree
     da = cKDTree(B).query(A)[0]

@@ -324,10 +324,12 @@ def optimize_batch(dec: DecoderWeights, opt: dict, instances: Sequence[Instance]
         return []
     cfg = opt_cfg_from_dict(opt)
     L = dec.latent_dim
+    from_cache = False                     # only a workspace the cache owns may be released when it has to grow
     if workspace is None and cache is not None:
         workspace = cache.get("ws")
         if workspace is not None and (workspace.handle is None or workspace.dec is not dec):
             workspace = None
+        from_cache = workspace is not None
     n_frame = int(opt["render"]["n_frame"])
     M = 0 if shape_only else cfg.n_sample_on_ray
     l = workspace.limits if workspace is not None else None
@@ -335,7 +337,7 @@ def optimize_batch(dec: DecoderWeights, opt: dict, instances: Sequence[Instance]
     pb = PackedBatch(instances, L, n_frame, device, joint=not shape_only,
                      F_cap=l.max_frames if l else None, R_cap=l.max_rays if l else None)
     if workspace is None or not workspace.fits(pb.B, pb.points_stride, pb.F, pb.R, M):
-        workspace = _grown_workspace(dec, workspace if cache is not None else None, pb.B, pb.points_stride, pb.F, pb.R, M)
+        workspace = _grown_workspace(dec, workspace if from_cache else None, pb.B, pb.points_stride, pb.F, pb.R, M)
         l = workspace.limits
         if not shape_only and (pb.F, pb.R) != (l.max_frames, l.max_rays):
             pb = PackedBatch(instances, L, n_frame, device, F_cap=l.max_frames, R_cap=l.max_rays)

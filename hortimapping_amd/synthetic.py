@@ -174,7 +174,7 @@ def _first_hit(sdf_fn, origins, dirs, t0, t1, n_march=48, n_bisect=18):
 
 def make_instance(Ws, bs, latent_dim, inst_id, n_pts=2048, n_frames=1, n_fg=32, n_bg=32,
                   seed_base=1000, r_max=0.08, sdf_fn_factory=None, z_sigma=0.07,
-                  pose_noise=0.005, pix_halfwidth=80.0, scale_init=1.0, z_true=None):
+                  pose_noise=0.005, pix_halfwidth=80.0, scale_init=1.0, z_true=None, baseline=0.02):
     """One synthetic fruit instance in the reference's caller-side data format.
 
     Returns a dict with fp32 arrays: ``latent0 (L,)``, ``T_ow0 (4,4)``, ``points_w (n_pts,3)``,
@@ -223,7 +223,7 @@ def make_instance(Ws, bs, latent_dim, inst_id, n_pts=2048, n_frames=1, n_fg=32, 
     for f in range(n_frames):
         T_wc = np.eye(4)
         if f > 0:
-            T_wc[:3, 3] = np.array([0.02 * f, -0.01 * f, 0.0])
+            T_wc[:3, 3] = np.array([baseline * f, -0.5 * baseline * f, 0.0])     # camera offsets (default 2 cm, -1 cm per frame)
         cam_o = T_wc[:3, 3]
         pc = centre - cam_o
         uv_c = (CAM_K @ (pc / pc[2]))[:2]

@@ -160,6 +160,15 @@ size_t hm_workspace_bytes(hm_workspace_t ws);
 int hm_workspace_profile(hm_workspace_t ws, int enable);
 int hm_workspace_profile_read(hm_workspace_t ws, double* ms_total, long long* launches);
 
+/* Measurement aid (the whole-iteration algorithmic flop count needs the data-dependent sizes): when
+ * enabled (enabling zeroes the sums), every iteration of hm_optimize_batch adds, over the instances active in it,
+ *   out5[0] instance-iterations, [1] SDF-term Jacobian queries (N_s; optimizer.py:163-190),
+ *   [2] forward-only ray samples K_v (ball-valid samples of the frames that count; loss.py:38-49, optimizer.py:130),
+ *   [3] ray samples that need the Jacobian K_g' (loss.py:160-185), [4] emitted rays V (rows of the depth / mask terms)
+ * with one extra one-block launch per iteration.  hm_workspace_counters_read synchronises `stream` and copies them. */
+int hm_workspace_counters(hm_workspace_t ws, int enable);
+int hm_workspace_counters_read(hm_workspace_t ws, long long* out5, void* stream);
+
 /* Replaces Optimizer.shape_pose_joint_opt (mode 0; optimizer.py:28-302) and Optimizer.shape_opt_deepsdf (mode 1;
  * optimizer.py:306-429) for a whole batch.  Enqueues cfg->max_iter iterations on `stream` with no host sync;
  * instances that converge / become invalid are frozen bit-exactly by device-side flags. */
@@ -183,6 +192,7 @@ int hm_render_residuals(hm_workspace_t ws, const hm_opt_cfg* cfg, const hm_batch
  * the f16x3 decoder kernel / of the solve kernel writes shader-clock stamps per stage into it (scripts/gpu_trace_*.py). */
 void hm_debug_set_trace(long long* d_buf);      /* [NSTAGE * 4 + 1] or NULL */
 void hm_debug_set_k5_trace(long long* d_buf);   /* [32] or NULL */
+void hm_debug_force_direct_solve(int on);        /* tests: 1 = every solve takes the blocked-Cholesky fallback of K5 */
 void hm_debug_set_k1p_trace(long long* d_buf);  /* [5 * 16] or NULL: per-stage stamps of the plain-fp16 decoder kernel */
 
 /* ---- unit hooks (tests): the device functions of the solve kernel / normal-equation kernel on caller-supplied values.
@@ -200,7 +210,10 @@ int hm_debug_huber(const float* d_res, int n, float threshold, float* d_rho, flo
 int hm_extract_surface(int B, const float* d_sdf, int n, float level, float cube_radius, int* d_offsets,
                        int* d_tri_count, float* d_tris, int max_tris, void* stream);
 /* the same with marching cubes: vertices exactly the grid-edge crossings (the vertex set of the reference's
- * scikit-image call, utils.py:573), at most 5 triangles per cell from a table generated at load time */
+ * scikit-image call, utils.py:573); the TRIANGULATION of a cell comes from a table generated at load time (one
+ * rule for ambiguous faces, no interior vertices) and may differ from scikit-image's Lewiner tables in ambiguous
+ * cells.  At most 8 triangles per cell (size d_tris for 8 * cells in the worst case; a count beyond max_tris is
+ * reported in d_tri_count, see above) */
 int hm_extract_surface_mc(int B, const float* d_sdf, int n, float level, float cube_radius, int* d_offsets,
                        int* d_tri_count, float* d_tris, int max_tris, void* stream);
 

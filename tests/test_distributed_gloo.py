@@ -92,6 +92,24 @@ def test_bench_refuses_a_gpu_count_that_does_not_match_the_launch():
     assert p.returncode != 0 and "WORLD_SIZE=1" in (p.stderr + p.stdout)
 
 
+def test_bench_spawns_its_own_ranks_when_started_bare():
+    """`python bench.py --gpus 2` with no launcher and no rank environment (the shape of the driver's N = 1 command with
+    a larger N) re-executes itself under torch.distributed.run: two ranks, one JSON line, the process-group size in it."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "TORCHELASTIC_RUN_ID",
+                                                              "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--stub-cpu", "--gpus", "2", "--latent", "32",
+                        "--steps", "2", "--warmup", "1", "--total", "37", "--batch", "8"], env=env, capture_output=True,
+                       text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["rccl_ranks"] == 2 and j["collective_backend"] == "gloo" and j["scaling"] == "strong"
+    assert j["config"]["instances_total"] == 37 and j["config"]["instances_per_gpu"] == 19
+
+
 def test_bench_shard_plan():
     sys.path.insert(0, ROOT)
     import bench

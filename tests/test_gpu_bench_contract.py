@@ -30,9 +30,41 @@ def test_bench_json_contract():
     r = d["roofline"]
     assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s") and r["peak"] > 0 and r["achieved"] > 0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and "traffic" in r
+    assert r["algorithmic_bytes_per_launch"] > 0 and "traffic_over_algorithmic" in r
+    st = r["step"]                                   # whole-iteration algorithmic flop from the device-side counters
+    cn = st["counts_per_step"]
+    assert cn["instance_iterations"] == 4 * 5 and cn["N_J_sdf_term"] == 4 * 5 * 1024
+    assert 0 < cn["N_F_ray_samples"] <= 4 * 5 * 1024 and 0 < cn["N_J_render"] <= cn["N_F_ray_samples"] and 0 < cn["V_rays"] <= 4 * 5 * 64
+    E = 32 + 7
+    A = ((cn["N_J_sdf_term"] + cn["N_J_render"]) * 7342080 + cn["N_F_ray_samples"] * 3671040
+         + 2 * (cn["N_J_sdf_term"] + 2 * cn["V_rays"]) * E * E + cn["instance_iterations"] * (2.0 / 3.0) * E ** 3)
+    assert abs(st["algorithmic_flop_per_step"] - A) <= 1e-9 * A and st["achieved"] > 0 and 0 < st["frac"] < 1
+    assert d["rccl_ranks"] == 1
     c = d["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] and c["sample"]
     assert abs(d["value"] - 4 * 2 / (d["ms_per_step"] * 2 * 1e-3)) < 0.02 * d["value"]     # value = units / time
+
+
+def test_bench_default_line_carries_the_secondary_objects():
+    """The default `python bench.py` line (BASELINE.json configs[1], 64 peppers x 200 iterations; one timed step here)
+    carries what SURVEY.md 8d asks beside the headline: the C2-sdf run, the whole-step roofline from device-side
+    counters, one rank's share of configs[3], and the labelled other arithmetics."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "1", "--no-cpu-baseline"],
+                         capture_output=True, text=True, timeout=1500, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["dtype"] == "f16x3" and d["config"]["instances_total"] == 64 and d["config"]["iterations"] == 200
+    for k in ("exact_f32", "mixed_f16x3f_f16b", "plain_f16", "trained_decoder", "batch_256", "c2_sdf", "configs3_rank_share"):
+        assert k in d and d[k]["value"] > 0, k
+    st = d["roofline"]["step"]
+    cn = st["counts_per_step"]
+    assert cn["instance_iterations"] == 64 * 200 and cn["N_J_sdf_term"] == 64 * 200 * 1024
+    assert st["algorithmic_flop_per_step"] > d["roofline"]["algorithmic_flop_per_launch"] * 200
+    sd = d["c2_sdf"]["roofline"]["step"]["counts_per_step"]
+    assert sd["N_J_sdf_term"] == 64 * 200 * 2048 and sd["N_F_ray_samples"] == 0 and sd["V_rays"] == 0
+    assert d["configs3_rank_share"]["instances"] == 512 and d["configs3_rank_share"]["roofline_step"]["counts_per_step"]["instance_iterations"] == 512 * 200
 
 
 def test_bench_strong_scaling_configs3_rank_share():

@@ -188,3 +188,56 @@ def test_intermediate_latent_sizes_full_loop(L):
         assert rel(r.latent, z) < TOL(2e-3, 5e-2) and rel(r.T_ow, T) < TOL(1e-4, 3e-3)
     assert res[2].status == 16 and res[2].iter_count == 0
     assert torch.equal(res[2].latent, empty.latent) and torch.equal(res[2].T_ow, empty.T_ow)
+
+
+def test_frame_subsampling_on_the_device_path():
+    """a14 (optimizer.py:77-78): SEVEN frames available, n_frame = 3 -> the reference optimises frames
+    np.linspace(0, 6, 3).astype(int) = [0, 3, 6].  The HIP path (host pick in PackedBatch + k_frame_setup per picked
+    frame) against the oracle, which restates the same pick; and against the first-three-frames run, which must differ
+    (so the pick is really exercised)."""
+    from hortimapping_amd import optimizer as HO, workloads as W
+    opt = W.c2_opt_cfg(max_iter=6, n_sample_on_ray=20, n_frame=3)
+    dec, od, dicts = make(32, 1, 0.04, (1.0, 0.75, 1.3), [11, 12], n_pts=600, n_frames=7, n_fg=120, n_bg=80)
+    assert list(HO.select_frames(7, 3)) == [0, 3, 6]
+    res = HO.optimize_batch(dec, opt, [W.to_instance(d, pose_known=True) for d in dicts])
+    for d, r in zip(dicts, res):
+        z, T, n = oracle_run(od, opt, d, True, ("a14", d["id"]))
+        assert r.iter_count == n == 6
+        assert rel(r.latent, z) < TOL(2e-3, 5e-2) and rel(r.T_ow, T) < TOL(1e-4, 3e-3)
+        first3 = W.to_instance(d, pose_known=True)
+        first3.render_data = {k: v[:3] for k, v in first3.render_data.items()}
+        r3 = HO.optimize_batch(dec, opt, [first3])[0]
+        assert rel(r3.latent, z) > 10 * rel(r.latent, z)               # frames [0, 1, 2] give a different answer
+
+
+def test_frame_turns_invalid_mid_trajectory_L256():
+    """a14 / loss.py:43-45 at the benchmark's latent size: frame 1 of these two-frame instances has only 8 rays x 16
+    samples, so its ball-valid sample count sits around the `< 100 -> None` rule and CHANGES SIDE as the free pose moves
+    (oracle trace: instance 4 loses the frame after iteration 0, instance 7 gains it at iteration 2 and loses it again at
+    4).  The HIP path must skip / keep the frame in the same iterations (device-side `valid_count >= min_valid` test in
+    the render chain): same iteration count, FRAME_SKIPPED reported, state within the oracle's own noise."""
+    import copy
+    from hortimapping_amd import optimizer as HO, workloads as W
+    from oracle import hm_oracle as O
+    opt = W.c2_opt_cfg(max_iter=8, n_sample_on_ray=16, n_frame=2)
+    from hortimapping_amd import synthetic as S
+    dec, od, _ = make(256, 2, 0.04, (1.0, 0.75, 1.3), [])
+    Ws, bs = S.fold_weight_norm(S.make_synthetic_decoder(256, seed=2, r0=0.04, aniso=(1.0, 0.75, 1.3)))
+    # instances generated with the numpy forward (not the GPU sampler): the case was picked on exactly these arrays
+    dicts = [S.make_instance(Ws, bs, 256, i, n_pts=128, n_frames=2, n_fg=48, n_bg=48) for i in (4, 7)]
+    for d in dicts:
+        for key in ("rays_fg", "rays_bg", "depth_fg", "depth_bg"):
+            d["render"][key][1] = d["render"][key][1][:4]
+    res = HO.optimize_batch(dec, opt, [W.to_instance(d, pose_known=False) for d in dicts])
+    for d, r in zip(dicts, res):
+        rd = {k: [torch.from_numpy(a) for a in v] for k, v in d["render"].items()}
+        tr = []
+        z, T, n = O.shape_pose_joint_opt(od, opt, torch.from_numpy(d["latent0"]), torch.from_numpy(d["T_ow0"]), rd,
+                                         torch.from_numpy(d["points_w"]), d["cube_radius"], pose_known=False, trace=tr)
+        rays = [t.n_rays for t in tr]
+        assert max(rays) - min(rays) >= 4, rays                        # the oracle really gained / lost the small frame
+        nz, nT, nn = oracle_noise(od, opt, d, False, ("inv256", d["id"]))
+        assert r.iter_count == n == 8
+        assert r.status & 64 and r.status & 8                          # FRAME_SKIPPED (informational) + max_iter
+        assert rel(r.latent, z) < max(TOL(2e-3, 1e-1), K_NOISE * nz), (rel(r.latent, z), nz)
+        assert rel(r.T_ow, T) < max(TOL(1e-4, 3e-3), K_NOISE * nT), (rel(r.T_ow, T), nT)

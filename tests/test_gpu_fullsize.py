@@ -120,38 +120,12 @@ def fullsize_fixture(which="analytic"):
     fs = {}
     sampler = DecoderWeights.from_params(params)
     sampler.set_precision("f32")
-    dirs = torch.from_numpy(MX.fibonacci_dirs(2000)).float().cuda()
-
-    def level_sets(latents):
-        """(n, 2000, 3) object-frame zero-level-set points of n shapes: bisection along fixed rays, batched."""
-        lat = torch.as_tensor(latents, dtype=torch.float32).cuda().contiguous()
-        n = lat.shape[0]
-        lo = torch.zeros(n, 2000, device="cuda")
-        hi = torch.full((n, 2000), 0.08, device="cuda")
-        nq = torch.full((n,), 2000, dtype=torch.int32, device="cuda")
-        pts4 = torch.zeros(n, 2048, 4, device="cuda")
-        for _ in range(24):
-            mid = 0.5 * (lo + hi)
-            pts4[:, :2000, :3] = dirs[None] * mid[..., None]
-            y, _ = ops.decode_batch(sampler, lat, pts4, nq, mode=0)
-            inside = y[:, :2000] < 0
-            lo = torch.where(inside, mid, lo)
-            hi = torch.where(inside, hi, mid)
-        return (dirs[None] * (0.5 * (lo + hi))[..., None]).double().cpu().numpy()
 
     def metrics(latents, T_ows):
         """per instance: (Chamfer-to-GT [m], translation error [m], rotation error [deg], scale ratio)"""
-        P = level_sets(latents)
-        out = np.zeros((len(latents), 4))
-        for i in range(len(latents)):
-            T_wo = np.linalg.inv(np.asarray(T_ows[i], dtype=np.float64))
-            pw = P[i] @ T_wo[:3, :3].T + T_wo[:3, 3]
-            out[i, 0] = MX.chamfer_distance(pw, fs["gt"][i])
-            out[i, 1:] = MX.pose_error(np.asarray(T_ows[i]), inp["T_wo_true"][i])
-        return out
+        return MX.completion_metrics(sampler, latents, T_ows, fs["gt"], inp["T_wo_true"])
     n = inp["latent0"].shape[0]
-    Pgt = level_sets(inp["z_true"])
-    fs["gt"] = [Pgt[i] @ inp["T_wo_true"][i][:3, :3].astype(np.float64).T + inp["T_wo_true"][i][:3, 3] for i in range(n)]
+    fs["gt"] = MX.ground_truth_points_world(sampler, inp["z_true"], inp["T_wo_true"])
     fs.update(inp=inp, rec=rec, metrics=metrics, n=n, params=params, oracle={})
     for mode in ("known", "free"):
         fs["oracle"][mode] = np.stack([metrics(rec[f"{mode}_latent"][p], rec[f"{mode}_T_ow"][p])

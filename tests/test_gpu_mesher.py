@@ -115,3 +115,40 @@ def test_surface_against_independent_marching_cubes_vertex_set(method):
             assert d2.max() < 1.8 * h                                    # extra (diagonal) vertices stay within a cell
         (m_mean, m_max), (c_mean, c_max) = LS.chamfer_to_crossings(m.sample_points_uniformly(20000, seed=1), cr)
         assert m_mean < 0.5 * h and m_max < 1.5 * h and c_mean < 0.25 * h        # 20000 samples: spacing ~ h / 4
+
+
+@pytest.mark.parametrize("decoder", ["analytic", "trained"])
+def test_no_cell_where_lewiner_would_add_a_vertex(decoder):
+    """The vertex-set claim of this row ("our marching-cubes vertices ARE the reference's") holds for skimage's Lewiner
+    variant only where it adds no cell-centre vertex, i.e. outside the sub-cases 6.1.2 / 7.3 / 10.2 / 12.2 / 13.x.  Those
+    need a cell whose sign configuration is one of the base cases 6, 7, 10, 12, 13: count the cells of every base case on
+    the grids that matter -- voxels_dim 40 (test_wild_completion.py:69-71) and 80, the C2 fruits of the bench (analytic
+    decoder, generating latents of the full-size fixture) and the trained decoder's learnt codes -- and require that NO
+    cell is in a centre-vertex base case (and none in the remaining ambiguous cases 3 and 4 either: on these smooth
+    fruit SDFs every cell is one of the unambiguous cases, where all marching-cubes variants give the same vertices)."""
+    import os
+    from golden_util import GOLDEN_DIR
+    from hortimapping_amd import synthetic as S
+    from hortimapping_amd.decoder import DecoderWeights
+    from hortimapping_amd.mesher import MeshExtractor
+    from oracle import level_set as LS
+    if decoder == "analytic":
+        p = S.make_synthetic_decoder(256, seed=2, r0=0.04, aniso=(1.0, 0.75, 1.3))
+        lat = torch.from_numpy(np.load(os.path.join(GOLDEN_DIR, "c2_fullsize_inputs.npz"))["z_true"][:16])
+    else:
+        with np.load(os.path.join(GOLDEN_DIR, "trained_decoder_L256.npz")) as f:
+            p = {k: (int(f[k]) if k in ("latent_dim", "hidden") else f[k]) for k in f.files}
+        lat = torch.from_numpy(np.asarray(p["codes"], dtype=np.float32)[:16])
+    dec = DecoderWeights.from_params(p)
+    dec.set_precision("f32")
+    total = np.zeros(15, np.int64)
+    for n in (40, 80):
+        mx = MeshExtractor(dec, code_len=256, voxels_dim=n, cube_radius=0.08)
+        for lo in range(0, lat.shape[0], 4):
+            for g in mx.decode_grids(lat[lo:lo + 4]).cpu().numpy():
+                h = LS.mc_case_histogram(g, 0.0)
+                assert h[1:].sum() > 500                                       # the surface is there
+                total += h
+    print(f"\n{decoder}: cells per marching-cubes base case 0..13 over 16 fruits x (40^3 + 80^3): {total[:14].tolist()}")
+    assert total[list(LS.CENTRE_VERTEX_CASES)].sum() == 0, total
+    assert total[list(LS.AMBIGUOUS_CASES)].sum() == 0, total

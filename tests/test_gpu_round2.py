@@ -113,17 +113,21 @@ def test_from_module_with_weight_norm_hooks_and_cache_invalidation():
 
 
 @pytest.mark.parametrize("precision", ["f32", "f16x3"])
-def test_solver_fast_path_and_direct_fallback_agree(precision, monkeypatch):
+def test_solver_fast_path_and_direct_fallback_agree(precision, request):
     """The solve kernel has two paths: Jacobi-preconditioned CG (taken when it reaches a 1e-7 relative residual, which
     the damped systems of the shipped configurations do in ~25 iterations) and the blocked Cholesky + fp64-refined
     triangular solves it falls back to.  Both must reproduce the reference's step (G8: delta <= 2e-4 vs its fp32
-    inverse, <= 5e-5 vs the fp64 oracle) and the golden trajectories; HM_FORCE_DIRECT_SOLVE=1 selects the fallback."""
+    inverse, <= 5e-5 vs the fp64 oracle) and the golden trajectories; the debug entry point
+    hm_debug_force_direct_solve(1) selects the fallback."""
     from hortimapping_amd import optimizer as HO
     from hortimapping_amd.decoder import DecoderWeights
     from oracle import hm_oracle as O
+    from hortimapping_amd import _lib
+    lib = _lib.lib()
+    request.addfinalizer(lambda: lib.hm_debug_force_direct_solve(0))
     out = {}
     for forced in ("0", "1"):
-        monkeypatch.setenv("HM_FORCE_DIRECT_SOLVE", forced)
+        lib.hm_debug_force_direct_solve(int(forced))
         g = GU.load("g8_one_iter_pepper256")
         dec = DecoderWeights.from_params(GU.decoder_params("pepper256")).set_precision(precision)
         cfg = GU.cfg_from_golden(g)
@@ -144,4 +148,5 @@ def test_solver_fast_path_and_direct_fallback_agree(precision, monkeypatch):
             r = HO.optimize_batch(dec32, GU.cfg_from_golden(t), [it], shape_only=(str(t["kind"]) == "sdf"))[0]
             assert r.iter_count == int(t["iter_count"]), (name, forced)
             assert GU.relmax(r.latent, t["z_out"]) < 1e-3 and GU.relmax(r.T_ow, t["T_out"]) < 1e-4, (name, forced)
+    lib.hm_debug_force_direct_solve(0)
     assert GU.relmax(out["0"], out["1"]) < 2e-5          # the two solvers agree far inside the reference's own rounding

@@ -119,3 +119,17 @@ def test_voxel_down_sample_matches_definition():
     k0 = tuple(idx[0])
     m = np.all(idx == np.array(k0), axis=1)
     assert np.abs(q - p[m].mean(0)).sum(axis=1).min() < 1e-12
+
+
+def test_marching_cubes_base_case_table():
+    """oracle/level_set.py's 256 -> base-case table: class sizes of the 14 classes (complement and mirror merged) and a
+    few hand-checked configurations; used by tests/test_gpu_mesher.py to bound where Lewiner's MC33 adds a vertex."""
+    import numpy as np
+    from oracle import level_set as LS
+    t = LS.mc_case_table()
+    assert np.bincount(t, minlength=14).tolist() == [2, 16, 24, 24, 8, 48, 48, 16, 6, 8, 6, 24, 24, 2]
+    assert t[0b00000001] == 1 and t[0b00000011] == 2 and t[0b00001001] == 3 and t[0b10000001] == 4
+    assert t[0b01101001] == 13 and t[0b10010110] == 13 and t[0b00001111] == 8 and t[0b11111110] == 1
+    vol = np.ones((3, 3, 3)); vol[1, 1, 1] = -1.0                           # one inside corner shared by the 8 cells
+    h = LS.mc_case_histogram(vol, 0.0)
+    assert h[1] == 8 and h.sum() == 8
