@@ -28,7 +28,53 @@ CANDIDATES = {
     "f4r256p2": (dict(n_pts=2048, n_frames=4, n_fg=128, n_bg=128, baseline=0.08), dict(n_sample_on_ray=16, n_frame=4)),
     "f4r256z3": (dict(n_pts=1024, n_frames=4, n_fg=128, n_bg=128, baseline=0.08, z_sigma=0.03), dict(n_sample_on_ray=16, n_frame=4)),
     "f8r256b": (dict(n_pts=1024, n_frames=8, n_fg=128, n_bg=128, baseline=0.05), dict(n_sample_on_ray=16, n_frame=8)),
+    # the same render block under the option blocks of the other shipped configurations (200 forced iterations)
+    "chal":    (dict(n_pts=1024, n_frames=4, n_fg=128, n_bg=128, baseline=0.08), dict(n_sample_on_ray=16, n_frame=4),
+                "shape_completion_challenge_pepper.yaml"),
+    "berry":   (dict(n_pts=1024, n_frames=4, n_fg=128, n_bg=128, baseline=0.08), dict(n_sample_on_ray=16, n_frame=4), "lab_berry.yaml"),
+    "labpep":  (dict(n_pts=1024, n_frames=4, n_fg=128, n_bg=128, baseline=0.08), dict(n_sample_on_ray=16, n_frame=4), "lab_pepper.yaml"),
+    # single knobs on the C2 option block
+    "lam1":    (dict(n_pts=1024, n_frames=4, n_fg=128, n_bg=128, baseline=0.08), dict(n_sample_on_ray=16, n_frame=4), {"lm.lm_lambda_0": 1.0}),
+    "creg2":   (dict(n_pts=1024, n_frames=4, n_fg=128, n_bg=128, baseline=0.08), dict(n_sample_on_ray=16, n_frame=4), {"weight.w_codereg": 1e-2}),
+    "creg1":   (dict(n_pts=1024, n_frames=4, n_fg=128, n_bg=128, baseline=0.08), dict(n_sample_on_ray=16, n_frame=4), {"weight.w_codereg": 1e-1}),
+    "norob":   (dict(n_pts=1024, n_frames=4, n_fg=128, n_bg=128, baseline=0.08), dict(n_sample_on_ray=16, n_frame=4), {"robust_iter": 1000}),
 }
+_BLK = (dict(n_pts=1024, n_frames=4, n_fg=128, n_bg=128, baseline=0.08), dict(n_sample_on_ray=16, n_frame=4))
+for _n, _o in {"lam3": {"lm.lm_lambda_0": 3.0}, "lam10": {"lm.lm_lambda_0": 10.0}, "lam30": {"lm.lm_lambda_0": 30.0},
+               "lam1creg1": {"lm.lm_lambda_0": 1.0, "weight.w_codereg": 1e-1},
+               "lam10creg1": {"lm.lm_lambda_0": 10.0, "weight.w_codereg": 1e-1},
+               "lam10creg2": {"lm.lm_lambda_0": 10.0, "weight.w_codereg": 1e-2},
+               "wd3": {"weight.w_depth": 5e-3, "weight.w_mask": 5e-5},
+               "lam10wd3": {"lm.lm_lambda_0": 10.0, "weight.w_depth": 5e-3, "weight.w_mask": 5e-5},
+               "lam1eye": {"lm.lm_lambda_0": 1.0, "lm.lm_eye": True}}.items():
+    CANDIDATES[_n] = _BLK + (_o,)
+# a more elongated fruit (decoder anisotropy) under lambda 1 / 10
+CANDIDATES["an_lam1"] = _BLK + ({"lm.lm_lambda_0": 1.0}, dict(aniso=(0.7, 1.0, 1.6)))
+CANDIDATES["an_lam10"] = _BLK + ({"lm.lm_lambda_0": 10.0}, dict(aniso=(0.7, 1.0, 1.6)))
+
+
+def build_cfg(W, ckw, extra):
+    """C2 option block (wild_pepper weights, forced iterations); `extra` = a shipped YAML whose opt block replaces it (its
+    render sizes and iteration control overridden) or a dict of dotted-key overrides."""
+    import yaml
+    cfg = W.c2_opt_cfg(max_iter=200, **ckw)
+    if isinstance(extra, str):
+        o = yaml.safe_load(open(os.path.join(ROOT, "configs", extra)))["opt"]
+        for sec, d in o.items():
+            if isinstance(d, dict):
+                for k, v in d.items():
+                    o[sec][k] = float(v) if isinstance(v, str) else v
+        o["converge"].update(cfg["converge"])
+        o["render"].update(n_sample_on_ray=ckw["n_sample_on_ray"], n_frame=ckw["n_frame"])
+        cfg = o
+    elif isinstance(extra, dict):
+        for k, v in extra.items():
+            ks = k.split(".")
+            if len(ks) == 1:
+                cfg[k] = v
+            else:
+                cfg[ks[0]][ks[1]] = v
+    return cfg
 PERTS = ("nominal", "points_up", "points_down", "pose0_up", "depth_up")
 
 
@@ -42,20 +88,25 @@ def main():
     from hortimapping_amd import metrics as MX, optimizer as HO, synthetic as S, workloads as W
     from hortimapping_amd.decoder import DecoderWeights
     L = 256
-    params = S.make_synthetic_decoder(L, seed=2, r0=0.04, aniso=(1.0, 0.75, 1.3))
-    dec = DecoderWeights.from_params(params)
-    sampler = DecoderWeights.from_params(params)
-    sampler.set_precision("f32")
-    Ws, bs = S.fold_weight_norm(params)
-    fac = W.gpu_sdf_factory(sampler)
+    modes = ("free",) if os.environ.get("WC_FREE_ONLY") else ("free", "known")
     for name in names:
-        ikw, ckw = CANDIDATES[name]
+        ikw, ckw = CANDIDATES[name][:2]
+        extra = CANDIDATES[name][2] if len(CANDIDATES[name]) > 2 else None
+        dkw = dict(aniso=(1.0, 0.75, 1.3))
+        if len(CANDIDATES[name]) > 3:
+            dkw.update(CANDIDATES[name][3])
+        params = S.make_synthetic_decoder(L, seed=2, r0=0.04, **dkw)
+        dec = DecoderWeights.from_params(params)
+        sampler = DecoderWeights.from_params(params)
+        sampler.set_precision("f32")
+        Ws, bs = S.fold_weight_norm(params)
+        fac = W.gpu_sdf_factory(sampler)
         t0 = time.time()
         dicts = [S.make_instance(Ws, bs, L, i, sdf_fn_factory=fac, **ikw) for i in range(n)]
         gt = MX.ground_truth_points_world(sampler, np.stack([d["z_true"] for d in dicts]), [d["T_wo_true"] for d in dicts])
         Ttrue = [d["T_wo_true"] for d in dicts]
-        cfg = W.c2_opt_cfg(max_iter=200, **ckw)
-        for mode in ("free", "known"):
+        cfg = build_cfg(W, ckw, extra)
+        for mode in modes:
             m = []
             for p in PERTS:
                 dec.set_precision(precision)

@@ -214,13 +214,15 @@ def test_frame_turns_invalid_mid_trajectory_L256():
     """a14 / loss.py:43-45 at the benchmark's latent size: frame 1 of these two-frame instances has only 8 rays x 16
     samples, so its ball-valid sample count sits around the `< 100 -> None` rule and CHANGES SIDE as the free pose moves
     (oracle trace: instance 4 loses the frame after iteration 0, instance 7 gains it at iteration 2 and loses it again at
-    4).  The HIP path must skip / keep the frame in the same iterations (device-side `valid_count >= min_valid` test in
-    the render chain): same iteration count, FRAME_SKIPPED reported, state within the oracle's own noise."""
-    import copy
-    from hortimapping_amd import optimizer as HO, workloads as W
+    4; the reference itself prints 'This frame is not valid' in exactly those iterations).  The HIP path must skip / keep
+    the frame in the same iterations (device-side `valid_count >= min_valid` test in the render chain): after EVERY
+    iteration count k = 1..8 the device-side counters of the last iteration (ball-valid samples of the frames that count,
+    Jacobian samples, emitted rays) equal the oracle's exactly, FRAME_SKIPPED is reported, and the state agrees -- to the
+    fp32 class while the trajectory is still short, and for the stable instance over all eight iterations (instance 7 is
+    one of the chaotic free-pose cases: its GPU-oracle difference triples per iteration from 1e-5, while every count
+    still matches)."""
+    from hortimapping_amd import optimizer as HO, synthetic as S, workloads as W
     from oracle import hm_oracle as O
-    opt = W.c2_opt_cfg(max_iter=8, n_sample_on_ray=16, n_frame=2)
-    from hortimapping_amd import synthetic as S
     dec, od, _ = make(256, 2, 0.04, (1.0, 0.75, 1.3), [])
     Ws, bs = S.fold_weight_norm(S.make_synthetic_decoder(256, seed=2, r0=0.04, aniso=(1.0, 0.75, 1.3)))
     # instances generated with the numpy forward (not the GPU sampler): the case was picked on exactly these arrays
@@ -228,16 +230,27 @@ def test_frame_turns_invalid_mid_trajectory_L256():
     for d in dicts:
         for key in ("rays_fg", "rays_bg", "depth_fg", "depth_bg"):
             d["render"][key][1] = d["render"][key][1][:4]
-    res = HO.optimize_batch(dec, opt, [W.to_instance(d, pose_known=False) for d in dicts])
-    for d, r in zip(dicts, res):
+    for d in dicts:
         rd = {k: [torch.from_numpy(a) for a in v] for k, v in d["render"].items()}
         tr = []
-        z, T, n = O.shape_pose_joint_opt(od, opt, torch.from_numpy(d["latent0"]), torch.from_numpy(d["T_ow0"]), rd,
-                                         torch.from_numpy(d["points_w"]), d["cube_radius"], pose_known=False, trace=tr)
+        O.shape_pose_joint_opt(od, W.c2_opt_cfg(max_iter=8, n_sample_on_ray=16, n_frame=2), torch.from_numpy(d["latent0"]),
+                               torch.from_numpy(d["T_ow0"]), rd, torch.from_numpy(d["points_w"]), d["cube_radius"],
+                               pose_known=False, trace=tr)
         rays = [t.n_rays for t in tr]
-        assert max(rays) - min(rays) >= 4, rays                        # the oracle really gained / lost the small frame
-        nz, nT, nn = oracle_noise(od, opt, d, False, ("inv256", d["id"]))
-        assert r.iter_count == n == 8
-        assert r.status & 64 and r.status & 8                          # FRAME_SKIPPED (informational) + max_iter
-        assert rel(r.latent, z) < max(TOL(2e-3, 1e-1), K_NOISE * nz), (rel(r.latent, z), nz)
-        assert rel(r.T_ow, T) < max(TOL(1e-4, 3e-3), K_NOISE * nT), (rel(r.T_ow, T), nT)
+        assert len(tr) == 8 and max(rays) - min(rays) >= 4, rays        # the oracle really gained / lost the small frame
+        states = {}
+        for k in (1, 2, 3, 4, 5, 6, 7, 8):
+            opt = W.c2_opt_cfg(max_iter=k, n_sample_on_ray=16, n_frame=2)
+            dbg = {}
+            r = HO.optimize_batch(dec, opt, [W.to_instance(d, pose_known=False)], debug=dbg)[0]
+            c = dbg["counts"][0].cpu().numpy()
+            assert r.iter_count == k and r.status & 8
+            assert (int(c[0]), int(c[1]), int(c[2])) == (tr[k - 1].n_valid, tr[k - 1].n_keep, tr[k - 1].n_rays), (d["id"], k, c)
+            states[k] = r
+        assert states[8].status & 64                                   # FRAME_SKIPPED (informational)
+        for k in ((2, 8) if d["id"] == 4 else (2,)):
+            opt = W.c2_opt_cfg(max_iter=k, n_sample_on_ray=16, n_frame=2)
+            z, T, n = O.shape_pose_joint_opt(od, opt, torch.from_numpy(d["latent0"]), torch.from_numpy(d["T_ow0"]), rd,
+                                             torch.from_numpy(d["points_w"]), d["cube_radius"], pose_known=False)
+            assert n == k
+            assert rel(states[k].latent, z) < TOL(2e-4, 5e-2) and rel(states[k].T_ow, T) < TOL(5e-5, 3e-3), (d["id"], k)
