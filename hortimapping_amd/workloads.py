@@ -34,6 +34,27 @@ def c2_opt_cfg(max_iter=200, n_sample_on_ray=16, n_frame=1):
     return o
 
 
+# The WELL-CONDITIONED full-size case: same sizes as C2 (L = 256, 8 x 512 decoder, 200 forced
+# iterations, free Sim(3) pose), but a 4-frame render block that observes the pose (4 x 128 rays x 16 samples, 8 cm camera
+# baseline), the render terms weighted 10 x lower and the LM damping of lab_berry.yaml (lm_lambda_0 = 1.0): under these
+# user-settable YAML values the reference's own 200-iteration result moves by ~1e-5 (not 1e-2) under a one-ulp input
+# change, so BASELINE.json's "within 1e-4 relative" can be tested outright, without a noise clause.
+WC_INSTANCE_KW = dict(n_pts=1024, n_frames=4, n_fg=64, n_bg=64, baseline=0.08)
+
+
+def wc_opt_cfg(max_iter=200):
+    o = c2_opt_cfg(max_iter=max_iter, n_sample_on_ray=16, n_frame=4)
+    o["weight"].update(w_depth=5e-3, w_mask=5e-5)
+    o["lm"]["lm_lambda_0"] = 1.0
+    return o
+
+
+def make_wc_instances(params, dec, ids, device="cuda"):
+    Ws, bs = S.fold_weight_norm(params)
+    fac = gpu_sdf_factory(dec, device) if (dec is not None and torch.cuda.is_available()) else None
+    return [S.make_instance(Ws, bs, int(params["latent_dim"]), i, sdf_fn_factory=fac, **WC_INSTANCE_KW) for i in ids]
+
+
 def gpu_sdf_factory(dec: DecoderWeights, device="cuda"):
     """sdf(x) callables backed by hm_decode_batch -- used only to *generate* synthetic observations quickly."""
     def factory(z_true):
@@ -83,3 +104,23 @@ def to_instance(d, pose_known=False) -> Instance:
     rd = {k: [torch.from_numpy(a) for a in v] for k, v in d["render"].items()}
     return Instance(torch.from_numpy(d["latent0"].copy()), torch.from_numpy(d["T_ow0"].copy()),
                     torch.from_numpy(d["points_w"]), rd, float(d["cube_radius"]), pose_known)
+
+
+def fixture_dicts(inp):
+    """Instance dicts (the layout of `synthetic.make_instance`) from an inputs fixture under tests/golden/: arrays
+    stacked over instances; render arrays carry a frame axis when the fixture has `n_frames` (multi-frame cases) and none
+    otherwise (the one-frame C2 fixture)."""
+    keys = ("T_wc", "rays_fg", "rays_bg", "depth_fg", "depth_bg")
+    out = []
+    for k in range(inp["latent0"].shape[0]):
+        if "n_frames" in getattr(inp, "files", inp):
+            rd = {key: [np.asarray(inp[key][k][f]) for f in range(int(inp["n_frames"][k]))] for key in keys}
+        else:
+            rd = {key: [np.asarray(inp[key][k])] for key in keys}
+        d = {"latent0": np.asarray(inp["latent0"][k]), "T_ow0": np.asarray(inp["T_ow0"][k]),
+             "points_w": np.asarray(inp["points_w"][k]), "render": rd, "cube_radius": float(inp["cube_radius"][k])}
+        for opt_key in ("z_true", "T_wo_true"):
+            if opt_key in getattr(inp, "files", inp):
+                d[opt_key] = np.asarray(inp[opt_key][k])
+        out.append(d)
+    return out

@@ -48,6 +48,24 @@ for _n, _o in {"lam3": {"lm.lm_lambda_0": 3.0}, "lam10": {"lm.lm_lambda_0": 10.0
                "lam10wd3": {"lm.lm_lambda_0": 10.0, "weight.w_depth": 5e-3, "weight.w_mask": 5e-5},
                "lam1eye": {"lm.lm_lambda_0": 1.0, "lm.lm_eye": True}}.items():
     CANDIDATES[_n] = _BLK + (_o,)
+for _n, _o in {"wd4": {"weight.w_depth": 5e-4, "weight.w_mask": 5e-6},
+               "wd3creg2": {"weight.w_depth": 5e-3, "weight.w_mask": 5e-5, "weight.w_codereg": 1e-2},
+               "wd3creg1": {"weight.w_depth": 5e-3, "weight.w_mask": 5e-5, "weight.w_codereg": 1e-1},
+               "wd4creg1": {"weight.w_depth": 5e-4, "weight.w_mask": 5e-6, "weight.w_codereg": 1e-1},
+               "wd4creg2": {"weight.w_depth": 5e-4, "weight.w_mask": 5e-6, "weight.w_codereg": 1e-2},
+               "wd3lam1": {"weight.w_depth": 5e-3, "weight.w_mask": 5e-5, "lm.lm_lambda_0": 1.0},
+               "wd4creg1lam1": {"weight.w_depth": 5e-4, "weight.w_mask": 5e-6, "weight.w_codereg": 1e-1, "lm.lm_lambda_0": 1.0},
+               "wd5creg1": {"weight.w_depth": 5e-5, "weight.w_mask": 5e-7, "weight.w_codereg": 1e-1}}.items():
+    CANDIDATES[_n] = _BLK + (_o,)
+_WL = {"weight.w_depth": 5e-3, "weight.w_mask": 5e-5, "lm.lm_lambda_0": 1.0}
+CANDIDATES["wl_c2blk"] = (dict(n_pts=1024, n_frames=1, n_fg=32, n_bg=32), dict(n_sample_on_ray=16, n_frame=1), _WL)
+CANDIDATES["wl_f2r128"] = (dict(n_pts=1024, n_frames=2, n_fg=64, n_bg=64, baseline=0.08), dict(n_sample_on_ray=16, n_frame=2), _WL)
+CANDIDATES["wl_f4r128"] = (dict(n_pts=1024, n_frames=4, n_fg=64, n_bg=64, baseline=0.08), dict(n_sample_on_ray=16, n_frame=4), _WL)
+CANDIDATES["wl_f4r256"] = _BLK + (_WL,)
+CANDIDATES["wl3_f4r256"] = _BLK + ({"weight.w_depth": 5e-3, "weight.w_mask": 5e-5, "lm.lm_lambda_0": 3.0},)
+CANDIDATES["wl_f4r256_w2"] = _BLK + ({"weight.w_depth": 1e-2, "weight.w_mask": 1e-4, "lm.lm_lambda_0": 1.0},)
+CANDIDATES["wd3creg1p4"] = (dict(n_pts=4096, n_frames=4, n_fg=128, n_bg=128, baseline=0.08), dict(n_sample_on_ray=16, n_frame=4),
+                            {"weight.w_depth": 5e-3, "weight.w_mask": 5e-5, "weight.w_codereg": 1e-1})
 # a more elongated fruit (decoder anisotropy) under lambda 1 / 10
 CANDIDATES["an_lam1"] = _BLK + ({"lm.lm_lambda_0": 1.0}, dict(aniso=(0.7, 1.0, 1.6)))
 CANDIDATES["an_lam10"] = _BLK + ({"lm.lm_lambda_0": 10.0}, dict(aniso=(0.7, 1.0, 1.6)))
@@ -76,6 +94,8 @@ def build_cfg(W, ckw, extra):
                 cfg[ks[0]][ks[1]] = v
     return cfg
 PERTS = ("nominal", "points_up", "points_down", "pose0_up", "depth_up")
+if os.environ.get("WC_PERTS16"):
+    PERTS = PERTS + tuple(f"points_jitter{k}" for k in range(12))
 
 
 def main():
@@ -122,6 +142,8 @@ def main():
                   f"{np.median(rel):.2e} p90 {np.percentile(rel, 90):.2e} max {rel.max():.2e}; dT noise max "
                   f"{1e3 * noise[:, 1].max():.2e} mm; dR max {noise[:, 2].max():.2e} deg; dS max {noise[:, 3].max():.2e}; "
                   f"instances with rel CD noise <= 3e-5: {(rel <= 3e-5).sum()}/{n}   [{time.time() - t0:.0f} s]", flush=True)
+            if os.environ.get("WC_DUMP"):
+                print("   rel CD noise per instance:", " ".join(f"{v:.1e}" for v in rel), flush=True)
 
 
 if __name__ == "__main__":

@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""GPU box: stability of the reference ALGORITHM on the candidates of the well-conditioned full-size case
+(tests/golden/wc_candidates.npz, `workloads.wc_opt_cfg`): the HIP path in EXACT fp32 on the nominal inputs and on the 16
+one-ulp perturbations of tests/golden/make_fullsize_records.py; per candidate the largest move of each parity metric,
+expressed as a fraction of BASELINE.json's outright tolerance (1e-4 * scale) = its `score`.  Written to
+gpurun_out/wc_selection.json; `tests/golden/make_wc_records.py records` keeps the most stable candidates and runs the
+CPU oracle on them.  This is a selection of INPUTS by the algorithm's own conditioning, not a parity statement."""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+
+
+def main():
+    precision = sys.argv[1] if len(sys.argv) > 1 else "f32"
+    argv, sys.argv = sys.argv, sys.argv[:1]
+    import make_fullsize_records as MF
+    sys.argv = argv
+    from hortimapping_amd import metrics as MX, optimizer as HO, synthetic as S, workloads as W
+    from hortimapping_amd.decoder import DecoderWeights
+    params = S.make_synthetic_decoder(256, seed=2, r0=0.04, aniso=(1.0, 0.75, 1.3))
+    dec = DecoderWeights.from_params(params)
+    dec.set_precision(precision)
+    sampler = DecoderWeights.from_params(params)
+    sampler.set_precision("f32")
+    cand = os.path.join(ROOT, "tests", "golden", "wc_candidates.npz")
+    if not os.path.exists(cand):
+        # generate the candidates here (ray casting against the decoder is minutes on the GPU, an hour in numpy); the
+        # fixture stores every input array explicitly, so where it was generated does not matter to any consumer
+        import make_wc_records as MW
+        n_cand = int(sys.argv[2]) if len(sys.argv) > 2 else 64
+        ds = W.make_wc_instances(params, sampler, list(range(n_cand)))
+        cand = os.path.join(ROOT, "gpurun_out", "wc_candidates.npz")
+        os.makedirs(os.path.dirname(cand), exist_ok=True)
+        np.savez_compressed(cand, **MW.stack_instances(ds))
+        print("generated", cand, flush=True)
+    inp = np.load(cand)
+    dicts = W.fixture_dicts(inp)
+    n = len(dicts)
+    gt = MX.ground_truth_points_world(sampler, inp["z_true"], inp["T_wo_true"])
+    cfg = W.wc_opt_cfg(max_iter=200)
+    perts = ("nominal", "points_up", "points_down", "pose0_up", "depth_up") + tuple(f"points_jitter{k}" for k in range(12))
+    m = []
+    for p in perts:
+        res = HO.optimize_batch(dec, cfg, [W.to_instance(MF.perturb(d, p), pose_known=False) for d in dicts])
+        assert all(r.iter_count == 200 and r.status == 8 for r in res), sorted({r.status for r in res})
+        m.append(MX.completion_metrics(sampler, torch.stack([r.latent for r in res]).numpy(), [r.T_ow.numpy() for r in res],
+                                       gt, inp["T_wo_true"]))
+        print(p, "done", flush=True)
+    m = np.stack(m)
+    noise = np.abs(m[1:] - m[0]).max(axis=0)                                    # (n, 4)
+    scale = np.stack([m[0][:, 0], np.maximum(m[0][:, 1], 1e-3), np.maximum(m[0][:, 2], 0.1), np.ones(n)], axis=1)
+    frac = noise / (1e-4 * scale)
+    score = frac.max(axis=1)
+    out = {"precision": precision, "perts": list(perts), "score": score.tolist(), "noise": noise.tolist(),
+           "nominal_metrics": m[0].tolist(),
+           "note": "score = max over (Chamfer-to-GT, translation, rotation, scale) of [largest deviation of 16 one-ulp input "
+                   f"perturbations] / [1e-4 * scale]; HIP path in {precision}, 200 iterations, workloads.wc_opt_cfg"}
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    json.dump(out, open(os.path.join(ROOT, "gpurun_out", "wc_selection.json"), "w"))
+    order = np.argsort(score)
+    print("score (fraction of the 1e-4 tolerance used by the algorithm's own noise), sorted:")
+    print(" ".join(f"{i}:{score[i]:.2f}" for i in order))
+    print(f"candidates with score <= 0.15: {(score <= 0.15).sum()}, <= 0.3: {(score <= 0.3).sum()}, <= 1: {(score <= 1).sum()} of {n}")
+
+
+if __name__ == "__main__":
+    main()

@@ -82,15 +82,18 @@ def test_fullsize_frozen_after_exit(precision):
 # decoder arithmetic, against CPU-oracle records committed as fixtures (tests/golden/make_fullsize_records.py: the
 # oracle on the nominal inputs and on sixteen 1e-7-relative input perturbations, 2,176 runs, ~2.5 h on 8 cores).
 # ----------------------------------------------------------------------------------------------------------------
-K_NOISE = 3.0          # a GPU result may sit K_NOISE x further from the oracle than the oracle's own perturbed runs
+K_NOISE = 3.0          # short-horizon tests: a GPU result may sit K_NOISE x further from the oracle than its perturbed runs
 REL_FLOOR = 1e-4       # BASELINE.json north_star: "Chamfer distance / pose error within 1e-4 relative"
-# The 200-iteration map is chaotic: every arithmetic (and every change of summation order, solver, tile order) is one more
-# draw from the heavy-tailed distribution the 16 perturbed oracle runs sample.  A 17th independent draw exceeds 3 x the
-# maximum of 16 with probability ~1 % per instance (measured: exact f32 1 of 64 in each mode, f16x3 0, with the build
-# these records were first used on; a different build moves WHICH instance), so the gate allows ONE instance per mode
-# beyond K_NOISE, held to K_OUTLIER instead, and prints it.
-N_OUTLIER = 1
-K_OUTLIER = 6.0
+# The 200-iteration map is chaotic where the problem is ill conditioned (free pose at the C2 size: the reference itself
+# moves by percents under a one-ulp input change; tests/test_fullsize_reference_cpu.py shows the ACTUAL reference and the
+# oracle share that noise).  Round 2 bounded every instance by 3 x the largest of its 16 perturbed oracle runs and needed a
+# one-outlier allowance -- a weak test with heavy tails.  The gate is now DISTRIBUTIONAL (tests/parity_stats.py): an
+# instance inside 1e-4 passes outright; for the others the rank of the GPU deviation among the 16 perturbed-run deviations
+# must be uniform over the instances (one-sided Kolmogorov-Smirnov test, alpha = 1e-3: "the GPU arithmetic is no worse than
+# a one-ulp input change"), per metric and pose mode, for exact f32 AND f16x3, with no outlier allowance.  K_GROSS is only
+# a tripwire for a wrong answer on a single instance (10 x the instance's own band).
+ALPHA = 1e-3
+K_GROSS = 10.0
 _FS = {}
 
 
@@ -149,14 +152,13 @@ def fullsize_instances(pose_known, which="analytic"):
 def test_full_batch_metric_parity(mode, precision, records):
     """`records` = "analytic": the 64 c2_joint instances of the bench (analytic decoder, 16 perturbed oracle runs each);
     "trained": 16 instances of the same workload on the TRAINED decoder (dense layers, 8 perturbed runs each).
-    For EVERY instance after 200 iterations:
-        |m_gpu - m_cpu| <= max(1e-4 * scale(m_cpu), K_NOISE * noise_i)        m = Chamfer-to-GT, pose errors
-    with noise_i = the largest deviation of the sixteen perturbed oracle runs of instance i from its nominal run (the
-    reference algorithm's own response to a 1e-7 relative input change).  The two fp32-class arithmetics (f32, f16x3)
-    must pass on all 64 but N_OUTLIER, which is held to K_OUTLIER x noise_i (see the constants); every instance outside
-    the K_NOISE bound is listed by id in the table and in the assertion message.  The per-instance table is written to
-    gpurun_out/r02_parity_fullsize_<mode>_<precision>.txt (copied to profiles/)."""
+    After 200 iterations, per metric m (Chamfer-to-GT as metrics_3d/chamfer_distance.py:16-26 defines it, translation /
+    rotation / scale error):  an instance with |m_gpu - m_cpu| <= 1e-4 * scale(m_cpu) passes outright; over the others the
+    ranks of |m_gpu - m_cpu| among the instance's perturbed-oracle deviations must pass the one-sided KS test against
+    the uniform law (parity_stats.gate).  Gated for the two fp32-class arithmetics (f32, f16x3); the mixed and fp16 modes
+    are reported.  The per-instance table goes to gpurun_out/r03_parity_<records>_<mode>_<precision>.txt (-> profiles/)."""
     import os
+    import parity_stats as PS
     from hortimapping_amd import optimizer as HO, workloads as W
     from hortimapping_amd.decoder import DecoderWeights
     fs = fullsize_fixture(records)
@@ -168,44 +170,106 @@ def test_full_batch_metric_parity(mode, precision, records):
     assert all(r.iter_count == n_iter and r.status == 8 for r in res)
     assert np.array_equal(fs["rec"][f"{mode}_iter_count"], np.full_like(fs["rec"][f"{mode}_iter_count"], n_iter))
     m_gpu = fs["metrics"](torch.stack([r.latent for r in res]).numpy(), [r.T_ow.numpy() for r in res])
+    _FS.setdefault("gpu", {})[(records, mode, precision)] = m_gpu
     m_all = fs["oracle"][mode]
     m_cpu, m_pert = m_all[0], m_all[1:]
-    noise = np.abs(m_pert - m_cpu[None]).max(axis=0)                       # (n, 4)
+    pert_dev = np.abs(m_pert - m_cpu[None])                                # (K, n, 4)
+    noise = pert_dev.max(axis=0)                                           # (n, 4)
     scale = np.stack([m_cpu[:, 0], np.maximum(m_cpu[:, 1], 1e-3), np.maximum(m_cpu[:, 2], 0.1),
                       np.ones(n)], axis=1)                                 # floors: 1 mm, 0.1 deg, unit scale ratio
-    tol = np.maximum(REL_FLOOR * scale, K_NOISE * noise)
-    tol_out = np.maximum(REL_FLOOR * scale, K_OUTLIER * noise)
+    floor = REL_FLOOR * scale
     dev = np.abs(m_gpu - m_cpu)
     names = ("chamfer", "t_err", "r_err", "scale")
+    gates = {names[k]: PS.gate(dev[:, k], pert_dev[:, :, k], floor[:, k], ALPHA) for k in range(4)}
+    gross = [(i, names[k]) for i in range(n) for k in range(4) if dev[i, k] > max(floor[i, k], K_GROSS * noise[i, k])]
     lines = [f"# c2_joint full batch ({records} decoder), {n} instances x {n_iter} LM iterations, pose_{mode}, GPU {precision} "
              "vs CPU oracle",
-             f"# tolerance per instance and metric: max({REL_FLOOR:g} * scale, {K_NOISE:g} * noise_i); noise_i = max deviation "
-             f"of {m_pert.shape[0]} perturbed oracle runs (points x(1+-1e-7), T_ow0 x(1+1e-7), depth_fg x(1+1e-7), "
-             "independent 1e-7 jitters of every point coordinate)",
-             "# id  CD_cpu[mm]  CD_gpu[mm]  relCD_gpu  relCD_noise  dT[mm] noise_T[mm]  dR[deg] noise_R[deg]  dS noise_S  verdict"]
-    bad = []
+             f"# gate per metric: inside {REL_FLOOR:g} * scale -> outright; else rank of the deviation among the {m_pert.shape[0]} "
+             "perturbed oracle runs of the instance (points x(1+-1e-7), T_ow0 x(1+1e-7), depth_fg x(1+1e-7), independent 1e-7 "
+             f"jitters of every point coordinate), one-sided KS over the ranked instances at alpha = {ALPHA:g}",
+             "# id  CD_cpu[mm]  CD_gpu[mm]  relCD_gpu  relCD_noise  dT[mm] noise_T[mm]  dR[deg] noise_R[deg]  dS noise_S  rank_CD"]
+    ucd = dict(zip(gates["chamfer"]["idx"].tolist(), gates["chamfer"]["u"].tolist()))
     for i in range(n):
-        ok = bool((dev[i] <= tol[i]).all())
-        if not ok:
-            bad.append((i, [names[k] for k in range(4) if dev[i, k] > tol[i, k]]))
         lines.append(f"{i:3d} {1e3 * m_cpu[i, 0]:10.5f} {1e3 * m_gpu[i, 0]:10.5f} {dev[i, 0] / m_cpu[i, 0]:9.2e} "
                      f"{noise[i, 0] / m_cpu[i, 0]:9.2e} {1e3 * dev[i, 1]:9.2e} {1e3 * noise[i, 1]:9.2e} {dev[i, 2]:9.2e} "
-                     f"{noise[i, 2]:9.2e} {dev[i, 3]:9.2e} {noise[i, 3]:9.2e}  {'ok' if ok else 'FAIL'}")
+                     f"{noise[i, 2]:9.2e} {dev[i, 3]:9.2e} {noise[i, 3]:9.2e}  {('%.2f' % ucd[i]) if i in ucd else 'outright'}")
     relcd, relnoise = dev[:, 0] / m_cpu[:, 0], noise[:, 0] / m_cpu[:, 0]
     lines.append(f"# relative Chamfer-to-GT difference vs the oracle: median {np.median(relcd):.2e} p90 "
                  f"{np.percentile(relcd, 90):.2e} max {relcd.max():.2e};  oracle perturbation noise: median "
                  f"{np.median(relnoise):.2e} p90 {np.percentile(relnoise, 90):.2e} max {relnoise.max():.2e}")
-    lines.append(f"# instances within 1e-4 relative Chamfer outright: {(relcd <= 1e-4).sum()} of {n}; failing the gate: "
-                 f"{[b[0] for b in bad]}")
+    for k in names:
+        g = gates[k]
+        lines.append(f"# {k:8s}: within 1e-4 outright {g['outright']:2d} of {n}; ranked {g['ranked']:2d}: mean rank {g['mean_rank']:.2f} "
+                     f"(0.5 = like a perturbed run), at the top rank {g['top_rank']}, KS+ {g['ks']:.3f}, p = {g['p']:.3f} "
+                     f"-> {'ok' if g['ok'] else 'FAIL'}")
+    lines.append(f"# beyond {K_GROSS:g} x the instance's own band (gross-error tripwire): {gross}")
     os.makedirs("gpurun_out", exist_ok=True)
     tag = "fullsize" if records == "analytic" else records
-    with open(os.path.join("gpurun_out", f"r02_parity_{tag}_{mode}_{precision}.txt"), "w") as f:
+    with open(os.path.join("gpurun_out", f"r03_parity_{tag}_{mode}_{precision}.txt"), "w") as f:
         f.write("\n".join(lines) + "\n")
-    print("\n".join(lines[-2:]))
+    print("\n" + "\n".join(lines[-6:]))
     if precision in ("f32", "f16x3"):          # the fp32-class arithmetics are gated; the other modes are reported
-        assert len(bad) <= N_OUTLIER, f"{precision} pose_{mode}: instances outside max(1e-4, {K_NOISE} x noise): {bad}"
-        for i, _ in bad:
-            assert bool((dev[i] <= tol_out[i]).all()), f"{precision} pose_{mode}: instance {i} beyond {K_OUTLIER} x noise"
+        for k in names:
+            assert gates[k]["ok"], f"{precision} pose_{mode} {k}: ranks not uniform (KS+ {gates[k]['ks']:.3f}, p {gates[k]['p']:.2e})"
+        assert not gross, f"{precision} pose_{mode}: beyond {K_GROSS} x the instance's own perturbation band: {gross}"
+
+
+@pytest.mark.parametrize("mode", ["known", "free"])
+def test_fullsize_against_reference_records(mode, precision):
+    """The same 200-iteration gate against records of the ACTUAL reference loop (tests/golden/c2_fullsize_reference.npz:
+    `Optimizer.shape_pose_joint_opt` of /root/reference run on 16 of the 64 instances, nominal + four one-ulp input
+    perturbations; generator tests/golden/make_reference_records.py).  Per metric: |m_gpu - m_reference| inside 1e-4
+    outright, or its rank among the REFERENCE's own four perturbed deviations uniform over the instances (one-sided KS,
+    pooled over the four metrics' ranked entries per instance being correlated, so Chamfer is gated alone and the pose
+    metrics are gated together); and the oracle's noise band that calibrates test_full_batch_metric_parity agrees with the
+    reference's within 2x (geometric mean)."""
+    import os
+    import parity_stats as PS
+    from golden_util import GOLDEN_DIR
+    from hortimapping_amd import optimizer as HO, workloads as W
+    from hortimapping_amd.decoder import DecoderWeights
+    if precision not in ("f32", "f16x3"):
+        pytest.skip("fp32-class arithmetics only")
+    fs = fullsize_fixture("analytic")
+    ref = np.load(os.path.join(GOLDEN_DIR, "c2_fullsize_reference.npz"))
+    ids = ref["inst_ids"]
+    m_gpu_all = _FS.get("gpu", {}).get(("analytic", mode, precision))
+    if m_gpu_all is None:
+        dec = DecoderWeights.from_params(fs["params"])
+        dec.set_precision(precision)
+        res = HO.optimize_batch(dec, W.c2_opt_cfg(max_iter=200), fullsize_instances(mode == "known", "analytic"))
+        m_gpu_all = fs["metrics"](torch.stack([r.latent for r in res]).numpy(), [r.T_ow.numpy() for r in res])
+    sub = {"gt": [fs["gt"][i] for i in ids], "T": fs["inp"]["T_wo_true"][ids]}
+    from hortimapping_amd import metrics as MX
+    sampler = DecoderWeights.from_params(fs["params"])
+    sampler.set_precision("f32")
+    m_ref = np.stack([MX.completion_metrics(sampler, ref[f"{mode}_latent"][p], ref[f"{mode}_T_ow"][p], sub["gt"], sub["T"])
+                      for p in range(ref[f"{mode}_latent"].shape[0])])                       # (5, 16, 4)
+    m_gpu = m_gpu_all[ids]
+    m_orc = fs["oracle"][mode][:, ids]                                                          # (17, 16, 4)
+    scale = np.stack([m_ref[0][:, 0], np.maximum(m_ref[0][:, 1], 1e-3), np.maximum(m_ref[0][:, 2], 0.1), np.ones(len(ids))], axis=1)
+    floor = REL_FLOOR * scale
+    pert_ref = np.abs(m_ref[1:] - m_ref[0])                                                    # (4, 16, 4)
+    pert_orc = np.abs(m_orc[1:5] - m_orc[0])                                                   # the same 4 perturbations
+    out = []
+    for who, m in (("gpu", m_gpu), ("oracle", m_orc[0])):
+        dev = np.abs(m - m_ref[0])
+        g_cd = PS.gate(dev[:, 0], pert_ref[:, :, 0], floor[:, 0], ALPHA)
+        g_pose = PS.gate(dev[:, 1:].reshape(-1), pert_ref[:, :, 1:].reshape(4, -1), floor[:, 1:].reshape(-1), ALPHA)
+        out.append(f"{who:6s} vs REFERENCE, pose_{mode}: rel CD deviation median {np.median(dev[:, 0] / m_ref[0][:, 0]):.2e} "
+                   f"(reference's own noise median {np.median(pert_ref.max(axis=0)[:, 0] / m_ref[0][:, 0]):.2e}); Chamfer: outright "
+                   f"{g_cd['outright']}/16, ranked mean {g_cd['mean_rank']:.2f} p {g_cd['p']:.3f}; pose metrics: outright "
+                   f"{g_pose['outright']}/48, ranked mean {g_pose['mean_rank']:.2f} p {g_pose['p']:.3f}")
+        assert g_cd["ok"] and g_pose["ok"], out[-1]
+        assert np.all(dev <= np.maximum(floor, K_GROSS * pert_ref.max(axis=0))), out[-1]
+    big = (pert_ref.max(axis=0) > floor) & (pert_orc.max(axis=0) > floor)
+    ratio = float(np.exp(np.mean(np.log(pert_orc.max(axis=0)[big] / pert_ref.max(axis=0)[big])))) if big.any() else 1.0
+    out.append(f"oracle noise / reference noise over the same four perturbations (geometric mean, {int(big.sum())} entries): {ratio:.2f}")
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open(os.path.join("gpurun_out", f"r03_parity_vs_reference_{mode}_{precision}.txt"), "w") as f:
+        f.write("\n".join(out) + "\n")
+    print("\n" + "\n".join(out))
+    assert 0.5 <= ratio <= 2.0, ratio
 
 
 def test_trained_decoder_vs_fp64_oracle(precision):
@@ -293,4 +357,60 @@ def test_trained_short_horizon_parity(mode, precision):
     bad = [i for i in range(len(res)) if dl[i] > max(1e-5, K_NOISE * noise_l[i]) or dT[i] > max(1e-5, K_NOISE * noise_T[i])]
     print(f"\n{precision} pose_{mode}, {n_iter} iterations: max |d latent| median {np.median(dl):.2e} (oracle noise "
           f"{np.median(noise_l):.2e}), max |d T_ow| median {np.median(dT):.2e} (noise {np.median(noise_T):.2e}); outside: {bad}")
-    assert len(bad) <= N_OUTLIER, bad
+    assert len(bad) <= 1, bad      # short horizon, max-of-8 band: one instance may sit just outside it
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# The well-conditioned full-size case: 1e-4 OUTRIGHT with a free pose (no noise clause, no rank statistics).
+# ----------------------------------------------------------------------------------------------------------------
+def test_wellconditioned_free_pose_parity(precision):
+    """Same sizes as the bench (L = 256, 8 x 512 decoder, 200 forced LM iterations) with a FREE Sim(3) pose, on a case
+    where the reference algorithm itself is stable: `workloads.wc_opt_cfg` (4 frames x 128 rays x 16 samples, render terms
+    weighted 10 x lower, lm_lambda_0 = 1.0 as in lab_berry.yaml) on the instances `tests/golden/make_wc_records.py` kept
+    (the candidates whose OWN response to 16 one-ulp input perturbations uses the smallest fraction of the tolerance; the
+    stored CPU-oracle records repeat that measurement with four perturbations and it is asserted below).  Gate, for
+    EVERY instance and the two fp32-class arithmetics:
+        |m_gpu - m_oracle| <= 1e-4 * scale(m_oracle)       m = Chamfer-to-GT, translation / rotation / scale error
+    -- BASELINE.json's "Chamfer distance / pose error within 1e-4 relative", outright."""
+    import os
+    from golden_util import GOLDEN_DIR
+    from hortimapping_amd import metrics as MX, optimizer as HO, synthetic as S, workloads as W
+    from hortimapping_amd.decoder import DecoderWeights
+    f_in, f_rec = os.path.join(GOLDEN_DIR, "wc_fullsize_inputs.npz"), os.path.join(GOLDEN_DIR, "wc_fullsize_oracle.npz")
+    inp, rec = np.load(f_in), np.load(f_rec)
+    n = inp["latent0"].shape[0]
+    n_iter = int(rec["n_iter"])
+    assert n >= 16 and n_iter == 200 and np.all(rec["free_iter_count"] == 200)
+    params = S.make_synthetic_decoder(L, seed=2, r0=0.04, aniso=(1.0, 0.75, 1.3))
+    sampler = DecoderWeights.from_params(params)
+    sampler.set_precision("f32")
+    gt = MX.ground_truth_points_world(sampler, inp["z_true"], inp["T_wo_true"])
+    m_orc = np.stack([MX.completion_metrics(sampler, rec["free_latent"][p], rec["free_T_ow"][p], gt, inp["T_wo_true"])
+                      for p in range(rec["free_latent"].shape[0])])
+    m_cpu = m_orc[0]
+    scale = np.stack([m_cpu[:, 0], np.maximum(m_cpu[:, 1], 1e-3), np.maximum(m_cpu[:, 2], 0.1), np.ones(n)], axis=1)
+    tol = REL_FLOOR * scale
+    noise = np.abs(m_orc[1:] - m_cpu).max(axis=0)
+    # the case IS well conditioned: the oracle's own perturbed runs stay inside a third of the tolerance on every instance
+    assert np.all(noise <= 0.34 * tol), (noise / tol).max(axis=0)
+    dec = DecoderWeights.from_params(params)
+    dec.set_precision(precision)
+    res = HO.optimize_batch(dec, W.wc_opt_cfg(max_iter=n_iter), [W.to_instance(d, pose_known=False) for d in W.fixture_dicts(inp)])
+    assert all(r.iter_count == n_iter and r.status == 8 for r in res)
+    m_gpu = MX.completion_metrics(sampler, torch.stack([r.latent for r in res]).numpy(), [r.T_ow.numpy() for r in res], gt,
+                                  inp["T_wo_true"])
+    dev = np.abs(m_gpu - m_cpu)
+    lines = [f"# well-conditioned full-size case, {n} instances x {n_iter} LM iterations, FREE Sim(3) pose, GPU {precision} vs CPU oracle",
+             "# id(candidate)  CD_cpu[mm]  relCD_gpu  relCD_oracle_noise   dT[mm]  dR[deg]  dS   (tolerance: 1e-4 x CD, 1e-4 x max(t_err, 1 mm), "
+             "1e-4 x max(r_err, 0.1 deg), 1e-4)"]
+    for i in range(n):
+        lines.append(f"{int(inp['inst_ids'][i]):3d} {1e3 * m_cpu[i, 0]:9.5f} {dev[i, 0] / m_cpu[i, 0]:9.2e} {noise[i, 0] / m_cpu[i, 0]:9.2e} "
+                     f"{1e3 * dev[i, 1]:9.2e} {dev[i, 2]:9.2e} {dev[i, 3]:9.2e}  {'ok' if np.all(dev[i] <= tol[i]) else 'FAIL'}")
+    lines.append(f"# largest fraction of the 1e-4 tolerance used: GPU {np.max(dev / tol):.2f} (per metric {np.round((dev / tol).max(axis=0), 2).tolist()}), "
+                 f"oracle's own perturbed runs {np.max(noise / tol):.2f}")
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open(os.path.join("gpurun_out", f"r03_parity_wellconditioned_free_{precision}.txt"), "w") as f:
+        f.write("\n".join(lines) + "\n")
+    print("\n" + lines[-1])
+    if precision in ("f32", "f16x3"):
+        assert np.all(dev <= tol), [(int(inp["inst_ids"][i]), (dev[i] / tol[i]).round(2).tolist()) for i in range(n) if np.any(dev[i] > tol[i])]
