@@ -38,10 +38,10 @@ PEAK_F16_MFMA_TFLOPS = 2500.0 # same table: "Peak BF16/FP16 MFMA ~2.5 PF dense"
 PRECISIONS = {
     # name: (peak the dominant kernel is priced against, kernel name, note)
     "f32": (PEAK_F32_MFMA_TFLOPS, "k_decoder<1,0>", "f32 = exact fp32 MFMA (v_mfma_f32_32x32x2_f32)"),
-    "f16x3": (PEAK_F16_MFMA_TFLOPS, "k_decoder_h<1,0,0>",
+    "f16x3": (PEAK_F16_MFMA_TFLOPS, "k_decoder_h<0,false>",
               "f16x3 = fp16 MFMA on hi/lo split operands (three passes per product), fp32 accumulate, results "
               "fp32-class: ~2^-22 relative per product"),
-    "f16x3f_f16b": (PEAK_F16_MFMA_TFLOPS, "k_decoder_h<1,0,1>",
+    "f16x3f_f16b": (PEAK_F16_MFMA_TFLOPS, "k_decoder_h<0,true>",
                     "mixed: forward (residuals) as f16x3, input-gradient backward (Jacobians) as ONE fp16 MFMA pass "
                     "on the hi parts (J ~1e-3 relative); not fp32-class, never the default line"),
     "f16": (PEAK_F16_MFMA_TFLOPS, "k_decoder_p<1,0>",
@@ -159,6 +159,7 @@ def parse_args(argv=None):
     ap.add_argument("--decoder", default="analytic", choices=["analytic", "trained"],
                     help="decoder weights: the analytic synthetic fruit (default, BASELINE workload) or the weights learnt "
                          "by scripts/train_synthetic_deepsdf.py (tests/golden/trained_decoder_L256.npz, L = 256 only)")
+    ap.add_argument("--split-render", action="store_true", help=argparse.SUPPRESS)   # A/B: round-2 launch sequence (hm_debug_split_render)
     ap.add_argument("--stub-cpu", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--share-gpu", action="store_true", help=argparse.SUPPRESS)   # tests: N ranks on ONE GPU over gloo
     ap.add_argument("--dump-records", default="", help=argparse.SUPPRESS)         # tests: rank 0 saves the gathered records
@@ -263,6 +264,8 @@ def main(argv=None, emit=True):
                           0 if shape_only else hcfg.n_sample_on_ray)          # ONE workspace, reused by every chunk
         init = [(p.latent.clone(), p.T_ow.clone()) for p in pbs]
         lib = _lib.lib()
+        if args.split_render:
+            lib.hm_debug_split_render(1)
         lib.hm_workspace_profile.argtypes = [ctypes.c_void_p, ctypes.c_int]
         lib.hm_workspace_profile_read.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double),
                                                   ctypes.POINTER(ctypes.c_longlong)]
@@ -330,12 +333,17 @@ def main(argv=None, emit=True):
     # the profiled launches are the SDF-term K1 launches of every chunk; price them per query
     queries_per_launch = n_s if not strong else None
 
-    def roofline(precision, ms_tot, n_launch):
+    def roofline(precision, ms_tot, n_launch, cnt=None, steps=1):
         peak, kname, _ = PRECISIONS[precision]
         avg_ms = ms_tot / max(1, n_launch)
         # all chunks of this rank have the same size except possibly the last: use the mean queries per launch
         q = (sum(int(p.n_points.sum().item()) for p in pbs) / len(pbs)) if queries_per_launch is None else queries_per_launch
         flops = q * FLOP_FWD_BWD
+        # In the joint loop the f16x3 decoder puts the forward-only tiles of the ball-valid ray samples into the SAME grid
+        # as the SDF-term forward+backward tiles (hm_decoder_h.hip, launch_decoder_h_main): the timed launch carries both.
+        fused = kind == "joint" and precision in ("f16x3", "f16x3f_f16b") and cnt is not None and not args.split_render
+        q_fwd = cnt[2] * steps / max(1, n_launch) if fused else 0.0
+        flops += q_fwd * FLOP_FWD
         achieved = flops / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
         traffic, tsrc, busy = None, None, None    # HBM/fabric bytes per launch: from committed PMC passes of the same workload
         tj = os.path.join(ROOT, TRAFFIC_FILE) if TRAFFIC_FILE else None
@@ -347,13 +355,16 @@ def main(argv=None, emit=True):
         # algorithmic bytes of one launch: per query 16 B in (float4 point), 4 B sdf + one (L+8)-float Jacobian row out; the
         # weight operands the kernel touches once (7 x 512^2 products each way; 4 B per weight in every arithmetic: fp32, or
         # fp16 hi + lo) -- what an ideal kernel with every tile sharing one weight fetch would move
-        alg_bytes = int(q * (16 + 4 + (L + 8) * 4) + 2 * 7 * 512 * 512 * 4)
-        r = {"bound": "mfma", "kernel": kname + " (SDF-term decoder forward + input-gradient backward)",
+        alg_bytes = int(q * (16 + 4 + (L + 8) * 4) + q_fwd * (16 + 4) + 2 * 7 * 512 * 512 * 4)
+        what = (" (one grid: SDF-term forward + input-gradient backward tiles and the forward-only tiles of the ray samples)"
+                if fused else " (SDF-term decoder forward + input-gradient backward)")
+        r = {"bound": "mfma", "kernel": kname + what,
              "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
              "traffic": traffic, "traffic_source": tsrc, "algorithmic_bytes_per_launch": alg_bytes,
              "traffic_over_algorithmic": (round(traffic / alg_bytes, 2) if traffic else None),
              "launches": n_launch, "avg_launch_ms": round(avg_ms, 4),
-             "algorithmic_flop_per_launch": int(flops)}
+             "algorithmic_flop_per_launch": int(flops),
+             "queries_per_launch": {"forward_backward": int(q), "forward_only": int(round(q_fwd))}}
         if busy is not None:                      # matrix-pipe utilisation (all MFMA issued, incl. the 3 passes of f16x3)
             r["mfma_pipe_busy_frac"] = busy
             r["mfma_pipe_busy_source"] = tsrc
@@ -430,7 +441,7 @@ def main(argv=None, emit=True):
         if stub:
             out["stub"] = "rank logic only (gloo, CPU stand-in for the GPU optimisation): NOT a measurement"
         else:
-            out["roofline"] = roofline(args.precision, ms_tot, n_launch)
+            out["roofline"] = roofline(args.precision, ms_tot, n_launch, counts, args.steps)
             out["roofline"]["step"] = step_roofline(args.precision, dt / args.steps * 1e3, counts)
     if not stub and not args.no_exact and world == 1 and not strong:
         # the same job in the other decoder arithmetics, one timed step each, for reference next to the primary line
@@ -438,10 +449,11 @@ def main(argv=None, emit=True):
             if other == args.precision:
                 continue
             dt2, ms2, nl2, allrec2 = measure(other, 1, 1)
+            cnt2 = count_step()                       # measure() left `other` selected
             l2, T2, _, _ = D.unpack_records(allrec2.cpu(), L)
             out[key] = {"value": round(n_total / dt2, 3), "unit": "instances/s", "steps": 1, "dtype": other,
                         "dtype_note": PRECISIONS[other][2], "ms_per_step": round(dt2 * 1e3, 3),
-                        "roofline": roofline(other, ms2, nl2),
+                        "roofline": roofline(other, ms2, nl2, cnt2, 1),
                         "max_abs_latent_diff_vs_primary": float((l2 - lat).abs().max()),
                         "max_abs_T_diff_vs_primary": float((T2 - T).abs().max()),
                         "diff_note": "free-pose 200-iteration trajectories amplify rounding noise; per-instance parity of "

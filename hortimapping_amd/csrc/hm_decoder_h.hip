@@ -11,6 +11,7 @@
 // Tiling, register-resident ReLU masks, latent folding and the VALU side paths are those of hm_decoder.hip
 // (reference: deepsdf/networks/deep_sdf_decoder.py:75-110, wild_completion/utils.py:112-193, loss.py:229-241).
 #include <stdlib.h>
+#include <string.h>
 
 #include "hm_common.h"
 #include "hm_internal.h"
@@ -22,19 +23,38 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
+// One decode job = a contiguous range of workgroups of a launch.  A launch carries up to two jobs (the LM iteration
+// puts the SDF-term forward+backward tiles and the forward-only tiles of the ray samples into ONE grid: 1024 + ~830 tiles
+// instead of 4 + 3.25 rounds of 256), so the job kind is a wave-uniform RUNTIME value:
+//   mode 0  forward only (sdf values); with `mask_out` it also saves the ReLU masks of every tile (512 B per query)
+//   mode 1  forward + input-gradient backward (sdf + Jacobian rows)
+//   mode 2  backward only: the queries are a GATHERED subset of an earlier mode-0 job (src_slot -> its compacted query
+//           index); sdf and ReLU masks come from that job's outputs, so the 8 forward stages are not recomputed.  Per
+//           query the arithmetic of the backward stages is exactly that of mode 1, hence bit-identical Jacobian rows.
+struct DecSeg {
+  const float* pts;      // [B][n_stride][4]
+  const int* n_q;        // [B]
+  float* y;              // [B][n_stride] (modes 0, 1) or nullptr
+  float* J;              // [B][n_stride][ldJ] (modes 1, 2)
+  uint2* mask_out;       // mode 0: [B][n_stride / 64][8 layers][512 threads] or nullptr
+  const uint2* mask_in;  // mode 2: the mode-0 job's mask_out
+  const int* src_slot;   // mode 2: [B][n_stride] query index in the mode-0 job
+  const float* y_in;     // mode 2: the mode-0 job's y  ([B][src_stride])
+  int n_stride;
+  int src_stride;        // mode 2: n_stride of the mode-0 job
+  int mode;
+  int pose_dim;
+};
+
 struct DecodeArgsH {
   DecoderDev dec;
-  const float* pts;
-  const int* n_q;
   const int* active;
   const float* c0;
   const float* c4;
-  float* y;
-  float* J;
-  int n_stride;
   int B;
   int ldJ;
-  int pose_dim;
+  int n_blocks0;         // workgroups of seg[0]; the rest belongs to seg[1]
+  DecSeg seg[2];
   long long* trace;    // optional [NSTAGE][4] shader-clock stamps of block 0 / wave 0 (perf analysis), or nullptr
 };
 
@@ -304,9 +324,49 @@ __device__ __forceinline__ void load_group(const f16x8* xh, const f16x8* xl, int
   case 0: OP(mk0); break; case 1: OP(mk1); break; case 2: OP(mk2); break; case 3: OP(mk3); break; \
   case 4: OP(mk4); break; case 5: OP(mk5); break; case 6: OP(mk6); break; default: OP(mk7); break;
 
-// BW1: precision 2 ("f16x3f_f16b"): the forward stages (residuals, ReLU masks) run the three-pass split product, the
-// eight backward stages (Jacobian rows) ONE fp16 pass on the hi parts -- 4 instead of 6 matrix passes per query.
-template <int MODE, int TAG, bool BW1>
+// G7 = d sdf / d h7 = (1 - y^2) * w8, masked by layer 7's ReLU pattern: the input of the first backward stage, written
+// into the activation planes (tail of EPI_FWD7 in modes 1, prologue of mode 2).  dyA / dyB: 1 - y^2 of this lane's two
+// queries (qa, 32 + qa).
+template <bool BW1>
+__device__ __forceinline__ void write_g7(f16x4* xh4, f16x4* xl4, const float* bl, uint2 mk, int mb0, int mb1, int hi,
+                                         int qa, float dyA, float dyB, f16x2 xm2) {
+#pragma unroll
+  for (int sl = 0; sl < 2; ++sl) {
+    const int mb = sl == 0 ? mb0 : mb1;
+    const uint32_t bits = sl == 0 ? mk.x : mk.y;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int f4 = mb * 32 + 8 * g + 4 * hi;
+      const f32x4 wv = *reinterpret_cast<const f32x4*>(bl + 8 * HID + f4);
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb) {
+        const float dy = nb == 0 ? dyA : dyB;
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = mask_keep(dy * wv[j], bits, mask_pos(g, nb, j));
+        if (BW1) hi_store(xh4, ((f4 >> 3) * TQ + nb * 32 + qa) * 2 + hi, v);
+        else {
+          f16x2 unused = xm2;      // dy * w8 cannot overflow where the forward did not: not tracked
+          split_store<false>(xh4, xl4, ((f4 >> 3) * TQ + nb * 32 + qa) * 2 + hi, f32x2{v[0], v[1]}, f32x2{v[2], v[3]}, unused);
+        }
+      }
+    }
+  }
+}
+
+// ReLU-mask word of a gathered query: the saved word holds, per row group g, one nibble for the source tile's query
+// block 0 (bits 31-28, 23-20, ...) and one for block 1 (27-24, 19-16, ...); move the nibbles of the source block
+// (nb_src) to the positions of the destination block (nb).
+__device__ __forceinline__ uint32_t mask_nibbles(uint32_t w, int nb_src, int nb) {
+  const uint32_t sel = nb_src == 0 ? (w & 0xF0F0F0F0u) : (w & 0x0F0F0F0Fu);
+  if (nb_src == nb) return sel;
+  return nb == 0 ? (sel << 4) : (sel >> 4);
+}
+
+// TAG only names the launch site in profiles (0: the iteration's main launch, 1: the render Jacobian launch, 2: the
+// decode API).  BW1: precision 2 ("f16x3f_f16b"): the forward stages (residuals, ReLU masks) run the three-pass split
+// product, the eight backward stages (Jacobian rows) ONE fp16 pass on the hi parts -- 4 instead of 6 matrix passes per query.
+template <int TAG, bool BW1>
 __global__ __launch_bounds__(512, 2) void k_decoder_h(const DecodeArgsH a) {
   __shared__ f16x8 xh[64 * TQ];    // 64 KiB: hi plane  X[k/8][q][8]
   __shared__ f16x8 xl[64 * TQ];    // 64 KiB: lo plane (scaled by 2^11)
@@ -317,31 +377,27 @@ __global__ __launch_bounds__(512, 2) void k_decoder_h(const DecodeArgsH a) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int b = blockIdx.x % a.B;                 // tile-major block order (see hm_decoder.hip)
-  const int q0 = (blockIdx.x / a.B) * TQ;
+  const int si = blockIdx.x >= (unsigned)a.n_blocks0 ? 1 : 0;
+  const DecSeg& sg = a.seg[si];
+  const int blk = si ? blockIdx.x - a.n_blocks0 : blockIdx.x;
+  const int mode = sg.mode;
+  const int b = blk % a.B;                        // tile-major block order (see hm_decoder.hip)
+  const int tile = blk / a.B;
+  const int q0 = tile * TQ;
   if (a.active != nullptr && a.active[b] == 0) return;
-  const int nq = a.n_q[b];
+  const int nq = sg.n_q[b];
   if (q0 >= nq) return;
   const int cnt = (nq - q0 < TQ) ? nq - q0 : TQ;
 
   const int L = a.dec.L, m = a.dec.m, mb_zx = a.dec.mb_zx;
-  const size_t qbase = (size_t)b * a.n_stride + q0;
+  const size_t qbase = (size_t)b * sg.n_stride + q0;
   const int qa = lane & 31;
   const int hi = lane >> 5;
-  const f32x4* pts4 = reinterpret_cast<const f32x4*>(a.pts);
+  const f32x4* pts4 = reinterpret_cast<const f32x4*>(sg.pts);
   f16x4* xh4 = reinterpret_cast<f16x4*>(xh);
   f16x4* xl4 = reinterpret_cast<f16x4*>(xl);
-
-  // stage 0 input: rows 0..2 = xyz, rows 3..15 = 0  (groups 0 and 1)
-  if (tid < TQ) {
-    const f32x4 p = pts4[qbase + tid];
-    const f32x2 zz = {0.f, 0.f};
-    f16x2 untracked = {(_Float16)0.f, (_Float16)0.f};     // query coordinates: far inside the fp16 range by contract
-    split_store<false>(xh4, xl4, (0 * TQ + tid) * 2 + 0, f32x2{p[0], p[1]}, f32x2{p[2], 0.f}, untracked);
-    split_store<false>(xh4, xl4, (0 * TQ + tid) * 2 + 1, zz, zz, untracked);
-    split_store<false>(xh4, xl4, (1 * TQ + tid) * 2 + 0, zz, zz, untracked);
-    split_store<false>(xh4, xl4, (1 * TQ + tid) * 2 + 1, zz, zz, untracked);
-  }
+  float* Jout = sg.J;
+  const int mb0 = w, mb1 = w + 8;
 
   uint2 mk0 = {0, 0}, mk1 = {0, 0}, mk2 = {0, 0}, mk3 = {0, 0}, mk4 = {0, 0}, mk5 = {0, 0}, mk6 = {0, 0},
         mk7 = {0, 0};
@@ -353,22 +409,60 @@ __global__ __launch_bounds__(512, 2) void k_decoder_h(const DecodeArgsH a) {
   // A tile that overflowed is poisoned instead (NaN sdf, NaN Jacobian rows), which the solver reports as
   // HM_STATUS_SOLVE_FAILED; the exact fp32 arithmetic (precision 0) has no such limit.
   f16x2 xm2 = {(_Float16)0.f, (_Float16)0.f};   // range guard: running max of |hi|, see track_max
-  const float* cbias0 = a.c0 + (size_t)b * HID;
-  const float* cbias4 = a.c4 + (size_t)b * HID;
-  // stage all forward biases in LDS: the epilogues then never wait on global memory
   bl[8 * HID + tid] = a.dec.w8[tid];
-  for (int i = tid; i < 8 * HID; i += 512) {
-    const StageDesc& sb = a.dec.st[i >> 9];
-    const float* src = sb.inst_bias == 1 ? cbias0 : (sb.inst_bias == 2 ? cbias4 : sb.bias);
-    bl[i] = src[i & (HID - 1)];
+
+  if (mode != 2) {
+    // stage 0 input: rows 0..2 = xyz, rows 3..15 = 0  (groups 0 and 1)
+    if (tid < TQ) {
+      const f32x4 p = pts4[qbase + tid];
+      const f32x2 zz = {0.f, 0.f};
+      f16x2 untracked = {(_Float16)0.f, (_Float16)0.f};     // query coordinates: far inside the fp16 range by contract
+      split_store<false>(xh4, xl4, (0 * TQ + tid) * 2 + 0, f32x2{p[0], p[1]}, f32x2{p[2], 0.f}, untracked);
+      split_store<false>(xh4, xl4, (0 * TQ + tid) * 2 + 1, zz, zz, untracked);
+      split_store<false>(xh4, xl4, (1 * TQ + tid) * 2 + 0, zz, zz, untracked);
+      split_store<false>(xh4, xl4, (1 * TQ + tid) * 2 + 1, zz, zz, untracked);
+    }
+    const float* cbias0 = a.c0 + (size_t)b * HID;
+    const float* cbias4 = a.c4 + (size_t)b * HID;
+    // stage all forward biases in LDS: the epilogues then never wait on global memory
+    for (int i = tid; i < 8 * HID; i += 512) {
+      const StageDesc& sb = a.dec.st[i >> 9];
+      const float* src = sb.inst_bias == 1 ? cbias0 : (sb.inst_bias == 2 ? cbias4 : sb.bias);
+      bl[i] = src[i & (HID - 1)];
+    }
+  } else {
+    // backward only: sdf and ReLU masks of this tile's queries come from the forward job they were gathered from
+    const int* slot_p = sg.src_slot + qbase;
+    const int tiles_src = sg.src_stride / TQ;
+    float dy[2] = {0.f, 0.f};
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+      const int q = nb * 32 + qa;
+      if (q >= cnt) continue;                                      // padding queries: masks 0 -> zero gradients
+      const int slot = slot_p[q];
+      const float yv = sg.y_in[(size_t)b * sg.src_stride + slot];
+      dy[nb] = 1.f - yv * yv;
+      if (hi == 0 && w == 0) sc[2048 + q] = yv;
+      const int nb_src = (slot >> 5) & 1;
+      const uint2* mp = sg.mask_in + (((size_t)b * tiles_src + (slot >> 6)) * 8) * 512 + (w * 64 + hi * 32 + (slot & 31));
+#define HM_GATHER(M, LAYER)                                                     \
+      { const uint2 v = mp[(LAYER) * 512];                                      \
+        M.x |= mask_nibbles(v.x, nb_src, nb); M.y |= mask_nibbles(v.y, nb_src, nb); }
+      HM_GATHER(mk0, 0) HM_GATHER(mk1, 1) HM_GATHER(mk2, 2) HM_GATHER(mk3, 3)
+      HM_GATHER(mk4, 4) HM_GATHER(mk5, 5) HM_GATHER(mk6, 6) HM_GATHER(mk7, 7)
+#undef HM_GATHER
+    }
+    __syncthreads();                                               // bl (lin8's row) and the sdf values are staged
+    y_keep = lane < cnt ? sc[2048 + lane] : 0.f;                   // only wave 0's value is used (final row store)
+    write_g7<BW1>(xh4, xl4, bl, mk7, mb0, mb1, hi, qa, dy[0], dy[1], xm2);
   }
 
-  constexpr int n_stage = MODE == 0 ? 8 : NSTAGE;
-  for (int s = 0; s < n_stage; ++s) {
+  const int s_begin = mode == 2 ? 8 : 0;
+  const int s_end = mode == 0 ? 8 : NSTAGE;
+  for (int s = s_begin; s < s_end; ++s) {
     const StageDesc& sd = a.dec.st[s];
     const StageDescH& sh = a.dec.sth[s];
     const int epi = sd.epi;
-    const int mb0 = w, mb1 = w + 8;
     const bool u0 = (mb0 >= sd.mb_lo) && (mb0 < sd.mb_hi);
     const bool u1 = (mb1 >= sd.mb_lo) && (mb1 < sd.mb_hi);
     const float us = sh.unscale;
@@ -376,7 +470,7 @@ __global__ __launch_bounds__(512, 2) void k_decoder_h(const DecodeArgsH a) {
     const bool tr = a.trace != nullptr && blockIdx.x == 0 && tid == 0;
     if (tr) a.trace[s * 4 + 0] = clock64();
 
-    if (MODE == 1 && (epi == EPI_BWD4 || epi == EPI_BWD0)) {
+    if (epi == EPI_BWD4 || epi == EPI_BWD0) {
       // stage the 512 x 4 xyz columns in LDS scratch (one 16-byte load per thread), then broadcast-read them
       reinterpret_cast<f32x4*>(sc)[tid] = reinterpret_cast<const f32x4*>(epi == EPI_BWD4 ? a.dec.w4x : a.dec.w0x)[tid];
       __syncthreads();
@@ -397,7 +491,7 @@ __global__ __launch_bounds__(512, 2) void k_decoder_h(const DecodeArgsH a) {
 
     acc[0][0] = zero16h(); acc[0][1] = zero16h();
     acc[1][0] = zero16h(); acc[1][1] = zero16h();
-    if (MODE == 1 && epi == EPI_BWD0 && u1) {
+    if (epi == EPI_BWD0 && u1) {
       // d sdf/d z so far (lin4's transpose) was parked in this tile's J rows (true units); this stage accumulates at
       // 2^shift, so seed the accumulators with it.  Parking it in L2 instead of 32 VGPRs across three stages is what
       // keeps the K loop free of spills.
@@ -407,7 +501,7 @@ __global__ __launch_bounds__(512, 2) void k_decoder_h(const DecodeArgsH a) {
       for (int nb = 0; nb < 2; ++nb) {
         const int q = nb * 32 + qa;
         if (q < cnt) {
-          const float* row = a.J + (qbase + q) * (size_t)a.ldJ;
+          const float* row = Jout + (qbase + q) * (size_t)a.ldJ;
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
             const f32x4 v = *reinterpret_cast<const f32x4*>(row + jz + 8 * g + 4 * hi);
@@ -422,7 +516,7 @@ __global__ __launch_bounds__(512, 2) void k_decoder_h(const DecodeArgsH a) {
       const f16x8* wp = reinterpret_cast<const f16x8*>(sh.wp);
       const f16x8* wp0 = wp + (size_t)(mb0 - sd.mb_lo) * sh.mb_stride + lane;
       const f16x8* wp1 = wp + (size_t)(mb1 - sd.mb_lo) * sh.mb_stride + lane;
-      if (BW1 && MODE == 1 && s >= 8) {
+      if (BW1 && s >= 8) {
         if (u0 && u1) gemm_loop_h1<true, true>(acc, wp0, wp1, sh.n_k16, xh, lane);
         else if (u0) gemm_loop_h1<true, false>(acc, wp0, wp1, sh.n_k16, xh, lane);
         else if (u1) gemm_loop_h1<false, true>(acc, wp0, wp1, sh.n_k16, xh, lane);
@@ -437,7 +531,7 @@ __global__ __launch_bounds__(512, 2) void k_decoder_h(const DecodeArgsH a) {
     if (tr) a.trace[s * 4 + 2] = clock64();
 
 
-    if (MODE == 0 || epi <= EPI_FWD7) {
+    if (epi <= EPI_FWD7) {
       const float* bias = bl + s * HID;
       uint2 mk = {0, 0};
       // lin3's rows m..m+2 (always rows 29..31 of their block: m = 509 - L, L % 32 == 0) carry xyz into the skip layer:
@@ -478,8 +572,10 @@ __global__ __launch_bounds__(512, 2) void k_decoder_h(const DecodeArgsH a) {
         if (sl == 0) mk.x = bits; else mk.y = bits;
       }
 #define HM_SET(M) M = mk
-      if (MODE == 1) switch (sd.layer) { HM_MASK_CASES(HM_SET) }
+      if (mode == 1) switch (sd.layer) { HM_MASK_CASES(HM_SET) }
 #undef HM_SET
+      if (mode == 0 && sg.mask_out != nullptr)       // saved for a later backward-only job over a subset of these queries
+        sg.mask_out[(((size_t)b * (sg.n_stride / TQ) + tile) * 8 + sd.layer) * 512 + tid] = mk;
 
       if (epi == EPI_FWD7) {
         __syncthreads();
@@ -505,36 +601,14 @@ __global__ __launch_bounds__(512, 2) void k_decoder_h(const DecodeArgsH a) {
         const float yv = tanhf(a8);
         y_keep = yv;
         if (w == 0) {
-          if (lane < cnt) a.y[qbase + lane] = yv;
+          if (lane < cnt) sg.y[qbase + lane] = yv;
           sc[2048 + lane] = 1.f - yv * yv;
         }
-        if (MODE == 0) return;
+        if (mode == 0) return;
         __syncthreads();
-        const float dyA = sc[2048 + qa], dyB = sc[2048 + 32 + qa];
-#pragma unroll
-        for (int sl = 0; sl < 2; ++sl) {
-          const int mb = sl == 0 ? mb0 : mb1;
-          const uint32_t bits = sl == 0 ? mk.x : mk.y;
-#pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            const int f4 = mb * 32 + 8 * g + 4 * hi;
-            const f32x4 wv = *reinterpret_cast<const f32x4*>(bl + 8 * HID + f4);
-#pragma unroll
-            for (int nb = 0; nb < 2; ++nb) {
-              const float dy = nb == 0 ? dyA : dyB;
-              float v[4];
-#pragma unroll
-              for (int j = 0; j < 4; ++j) v[j] = mask_keep(dy * wv[j], bits, mask_pos(g, nb, j));
-              if (BW1) hi_store(xh4, ((f4 >> 3) * TQ + nb * 32 + qa) * 2 + hi, v);
-              else {
-                f16x2 unused = xm2;      // dy * w8 cannot overflow where the forward did not: not tracked
-                split_store<false>(xh4, xl4, ((f4 >> 3) * TQ + nb * 32 + qa) * 2 + hi, f32x2{v[0], v[1]}, f32x2{v[2], v[3]}, unused);
-              }
-            }
-          }
-        }
+        write_g7<BW1>(xh4, xl4, bl, mk, mb0, mb1, hi, qa, sc[2048 + qa], sc[2048 + 32 + qa], xm2);
       }
-    } else if (MODE == 1 && (epi == EPI_BWD || epi == EPI_BWD4)) {
+    } else if (epi == EPI_BWD || epi == EPI_BWD4) {
       uint2 mk;
 #define HM_GET(M) mk = M
       switch (sd.layer) { HM_MASK_CASES(HM_GET) }
@@ -551,7 +625,7 @@ __global__ __launch_bounds__(512, 2) void k_decoder_h(const DecodeArgsH a) {
             for (int nb = 0; nb < 2; ++nb) {
               const int q = nb * 32 + qa;
               if (q < cnt) {
-                float* row = a.J + (qbase + q) * (size_t)a.ldJ;
+                float* row = Jout + (qbase + q) * (size_t)a.ldJ;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                   f32x4 v;
@@ -590,14 +664,14 @@ __global__ __launch_bounds__(512, 2) void k_decoder_h(const DecodeArgsH a) {
           }
         }
       }
-    } else if (MODE == 1) {  // EPI_BWD0
+    } else {  // EPI_BWD0
       if (u1) {
         const int jz = (mb1 - mb_zx) * 32;
 #pragma unroll
         for (int nb = 0; nb < 2; ++nb) {
           const int q = nb * 32 + qa;
           if (q < cnt) {
-            float* row = a.J + (qbase + q) * (size_t)a.ldJ;
+            float* row = Jout + (qbase + q) * (size_t)a.ldJ;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
               f32x4 v;
@@ -611,8 +685,8 @@ __global__ __launch_bounds__(512, 2) void k_decoder_h(const DecodeArgsH a) {
     }
   }
 
-  if (a.trace != nullptr && blockIdx.x == 0 && tid == 0) a.trace[n_stage * 4] = clock64();
-  if (MODE == 0) return;
+  if (a.trace != nullptr && blockIdx.x == 0 && tid == 0) a.trace[NSTAGE * 4] = clock64();
+  if (mode == 0) return;
   if (__any(!(fmaxf((float)xm2[0], (float)xm2[1]) < 65504.f))) gx0 = __builtin_nanf("");
   sc[(w * 4 + 0) * 64 + lane] = gx0;
   sc[(w * 4 + 1) * 64 + lane] = gx1;
@@ -627,14 +701,14 @@ __global__ __launch_bounds__(512, 2) void k_decoder_h(const DecodeArgsH a) {
       g2 += sc[(i * 4 + 2) * 64 + lane];
     }
     const f32x4 p = pts4[qbase + lane];
-    float* row = a.J + (qbase + lane) * (size_t)a.ldJ + L;
+    float* row = Jout + (qbase + lane) * (size_t)a.ldJ + L;
     row[7] = y_keep;
     row[0] = g0; row[1] = g1; row[2] = g2;
-    if (a.pose_dim != 0) {
+    if (sg.pose_dim != 0) {
       row[3] = g2 * p[1] - g1 * p[2];
       row[4] = g0 * p[2] - g2 * p[0];
       row[5] = g1 * p[0] - g0 * p[1];
-      if (a.pose_dim == 7) row[6] = g0 * p[0] + g1 * p[1] + g2 * p[2];
+      if (sg.pose_dim == 7) row[6] = g0 * p[0] + g1 * p[1] + g2 * p[2];
     }
   }
 }
@@ -646,24 +720,86 @@ extern "C" void hm_debug_set_trace(long long* d_buf) { g_trace = d_buf; }
 
 namespace hm {
 
+namespace {
+
+template <int TAG>
+int launch_h(const hm_decoder_s* dec, DecodeArgsH& a, int grid, hipStream_t stream) {
+  if (grid == 0) return 0;
+  a.dec = dec->dev;
+  a.trace = g_trace;
+  if (dec->precision == 2) hipLaunchKernelGGL((k_decoder_h<TAG, true>), dim3(grid), dim3(512), 0, stream, a);
+  else hipLaunchKernelGGL((k_decoder_h<TAG, false>), dim3(grid), dim3(512), 0, stream, a);
+  HM_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+DecSeg plain_seg(const float* d_pts, const int* d_nq, int n_stride, float* d_y, float* d_J, int pose_dim, int mode) {
+  DecSeg s;
+  memset(&s, 0, sizeof(s));
+  s.pts = d_pts; s.n_q = d_nq; s.y = d_y; s.J = d_J; s.n_stride = n_stride; s.mode = mode; s.pose_dim = pose_dim;
+  return s;
+}
+
+}  // namespace
+
 int launch_decoder_h(const hm_decoder_s* dec, int B, const float* d_pts, const int* d_nq, const int* d_active,
                      int n_stride, const float* d_c0, const float* d_c4, float* d_y, float* d_J, int ldJ,
                      int pose_dim, int mode, hipStream_t stream, int tag) {
   DecodeArgsH a;
-  a.dec = dec->dev;
-  a.pts = d_pts; a.n_q = d_nq; a.active = d_active; a.c0 = d_c0; a.c4 = d_c4;
-  a.y = d_y; a.J = d_J; a.n_stride = n_stride; a.B = B; a.ldJ = ldJ; a.pose_dim = pose_dim;
-  a.trace = g_trace;
-  const int grid = B * (n_stride / TQ);
-  if (grid == 0) return 0;
-  const bool bw1 = dec->precision == 2;
-  if (mode == 0) hipLaunchKernelGGL((k_decoder_h<0, 0, false>), dim3(grid), dim3(512), 0, stream, a);   // forward only
-  else if (tag == 0 && !bw1) hipLaunchKernelGGL((k_decoder_h<1, 0, false>), dim3(grid), dim3(512), 0, stream, a);
-  else if (tag == 0) hipLaunchKernelGGL((k_decoder_h<1, 0, true>), dim3(grid), dim3(512), 0, stream, a);
-  else if (!bw1) hipLaunchKernelGGL((k_decoder_h<1, 1, false>), dim3(grid), dim3(512), 0, stream, a);
-  else hipLaunchKernelGGL((k_decoder_h<1, 1, true>), dim3(grid), dim3(512), 0, stream, a);
-  HM_CHECK_HIP(hipGetLastError());
-  return 0;
+  memset(&a, 0, sizeof(a));
+  a.active = d_active; a.c0 = d_c0; a.c4 = d_c4; a.B = B; a.ldJ = ldJ;
+  a.seg[0] = plain_seg(d_pts, d_nq, n_stride, d_y, d_J, pose_dim, mode);
+  a.seg[1] = a.seg[0];
+  a.n_blocks0 = B * (n_stride / TQ);
+  if (tag == 0) return launch_h<0>(dec, a, a.n_blocks0, stream);
+  if (tag == 1) return launch_h<1>(dec, a, a.n_blocks0, stream);
+  return launch_h<2>(dec, a, a.n_blocks0, stream);
+}
+
+// The LM iteration's main launch: SDF-term forward+backward tiles (long) first, then the forward-only tiles of the
+// ball-valid ray samples (short), which also save their ReLU masks for the render Jacobian launch.
+int launch_decoder_h_main(const hm_decoder_s* dec, int B, const int* d_active, const float* d_c0, const float* d_c4,
+                          int ldJ, const float* d_ptsS, const int* d_nS, int nS_stride, float* d_yS, float* d_JS,
+                          int pose_dim, const float* d_ptsR, const int* d_nR, int nR_stride, float* d_yR,
+                          void* d_maskR, hipStream_t stream) {
+  DecodeArgsH a;
+  memset(&a, 0, sizeof(a));
+  a.active = d_active; a.c0 = d_c0; a.c4 = d_c4; a.B = B; a.ldJ = ldJ;
+  a.seg[0] = plain_seg(d_ptsS, d_nS, nS_stride, d_yS, d_JS, pose_dim, 1);
+  a.seg[1] = plain_seg(d_ptsR, d_nR, nR_stride, d_yR, nullptr, 0, 0);
+  a.seg[1].mask_out = static_cast<uint2*>(d_maskR);
+  a.n_blocks0 = B * (nS_stride / TQ);
+  return launch_h<0>(dec, a, a.n_blocks0 + B * (nR_stride / TQ), stream);
+}
+
+// forward-only over the ray samples with mask saving (the functional render API, which has no SDF term beside it)
+int launch_decoder_h_fwd_masks(const hm_decoder_s* dec, int B, const int* d_active, const float* d_c0,
+                               const float* d_c4, const float* d_ptsR, const int* d_nR, int nR_stride, float* d_yR,
+                               void* d_maskR, hipStream_t stream) {
+  DecodeArgsH a;
+  memset(&a, 0, sizeof(a));
+  a.active = d_active; a.c0 = d_c0; a.c4 = d_c4; a.B = B; a.ldJ = 0;
+  a.seg[0] = plain_seg(d_ptsR, d_nR, nR_stride, d_yR, nullptr, 0, 0);
+  a.seg[0].mask_out = static_cast<uint2*>(d_maskR);
+  a.seg[1] = a.seg[0];
+  a.n_blocks0 = B * (nR_stride / TQ);
+  return launch_h<2>(dec, a, a.n_blocks0, stream);
+}
+
+// The render Jacobian launch: backward only over the gathered with-grad samples (masks + sdf from the main launch).
+int launch_decoder_h_bwd(const hm_decoder_s* dec, int B, const int* d_active, const float* d_c0, const float* d_c4,
+                         int ldJ, const float* d_ptsG, const int* d_nG, int nG_stride, float* d_JG, int pose_dim,
+                         const int* d_srcG, const float* d_yR, const void* d_maskR, int nR_stride,
+                         hipStream_t stream) {
+  DecodeArgsH a;
+  memset(&a, 0, sizeof(a));
+  a.active = d_active; a.c0 = d_c0; a.c4 = d_c4; a.B = B; a.ldJ = ldJ;
+  a.seg[0] = plain_seg(d_ptsG, d_nG, nG_stride, nullptr, d_JG, pose_dim, 2);
+  a.seg[0].mask_in = static_cast<const uint2*>(d_maskR);
+  a.seg[0].src_slot = d_srcG; a.seg[0].y_in = d_yR; a.seg[0].src_stride = nR_stride;
+  a.seg[1] = a.seg[0];
+  a.n_blocks0 = B * (nG_stride / TQ);
+  return launch_h<1>(dec, a, a.n_blocks0, stream);
 }
 
 }  // namespace hm

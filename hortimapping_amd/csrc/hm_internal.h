@@ -87,6 +87,8 @@ struct RenderBuffers {
   float* coefG;            // [B][nG_stride][2]
   float* JG;               // [B][nG_stride][ldJ]
   float* yG;               // [B][nG_stride]
+  int* srcG;               // [B][nG_stride]   slot (index in ptsRc / sdfR order) each Jacobian sample was gathered from
+  void* maskR;             // [B][nR_stride / 64][8][512] uint2: ReLU masks saved by the f16x3 forward pass over ptsRc
   float* JR;               // [B][2*F*R][ldJ]   depth rows then mask rows
   int nR_stride, nG_stride;
 };
@@ -101,6 +103,19 @@ int launch_decoder(const hm_decoder_s* dec, int B, const float* d_pts, const int
 int launch_decoder_h(const hm_decoder_s* dec, int B, const float* d_pts, const int* d_nq, const int* d_active,
                      int n_stride, const float* d_c0, const float* d_c4, float* d_y, float* d_J, int ldJ,
                      int pose_dim, int mode, hipStream_t stream, int tag);
+
+// f16x3 decoder, job-list launches of the LM iteration (hm_decoder_h.hip)
+int launch_decoder_h_main(const hm_decoder_s* dec, int B, const int* d_active, const float* d_c0, const float* d_c4,
+                          int ldJ, const float* d_ptsS, const int* d_nS, int nS_stride, float* d_yS, float* d_JS,
+                          int pose_dim, const float* d_ptsR, const int* d_nR, int nR_stride, float* d_yR,
+                          void* d_maskR, hipStream_t stream);
+int launch_decoder_h_fwd_masks(const hm_decoder_s* dec, int B, const int* d_active, const float* d_c0,
+                               const float* d_c4, const float* d_ptsR, const int* d_nR, int nR_stride, float* d_yR,
+                               void* d_maskR, hipStream_t stream);
+int launch_decoder_h_bwd(const hm_decoder_s* dec, int B, const int* d_active, const float* d_c0, const float* d_c4,
+                         int ldJ, const float* d_ptsG, const int* d_nG, int nG_stride, float* d_JG, int pose_dim,
+                         const int* d_srcG, const float* d_yR, const void* d_maskR, int nR_stride,
+                         hipStream_t stream);
 
 int launch_decoder_p(const hm_decoder_s* dec, int B, const float* d_pts, const int* d_nq, const int* d_active,
                      int n_stride, const float* d_c0, const float* d_c4, float* d_y, float* d_J, int ldJ,

@@ -104,6 +104,9 @@ void carve(hm_workspace_s* w, Carver& c) {
   rb.coefG = c.take<float>((size_t)B * w->nG_stride * 2);
   rb.JG = c.take<float>((size_t)B * w->nG_stride * w->ldJ);
   rb.yG = c.take<float>((size_t)B * w->nG_stride);
+  rb.srcG = c.take<int>((size_t)B * w->nG_stride);
+  // ReLU masks of the forward pass over the ray samples (f16x3 decoder): 512 B per sample slot
+  rb.maskR = c.take<unsigned long long>((size_t)B * (w->nR_stride / TQ) * 8 * 512);
   rb.JR = c.take<float>((size_t)B * 2 * nray * w->ldJ);
   rb.nR_stride = w->nR_stride;
   rb.nG_stride = w->nG_stride;
@@ -218,19 +221,42 @@ void bind_inputs(RenderBuffers& rb, const hm_batch* bt) {
   rb.n_frames = bt->d_n_frames; rb.cube_radius = bt->d_cube_radius;
 }
 
-// render front end + Jacobian pass + per-ray reduce for the current state (optimizer.py:93-132)
+// The f16x3 decoder (precisions 1, 2) runs the render chain's Jacobian pass BACKWARD-ONLY: its forward pass over the
+// ball-valid samples saves the ReLU masks, so the with-grad samples need no second forward.  g_split_render = 1 selects
+// the round-2 sequence (separate forward launch, forward+backward over the with-grad samples) for A/B runs and for the
+// test that both give the same bits.
+int g_split_render = 0;
+
+bool fused_path(const hm_workspace_s* ws) { return (ws->dec->precision == 1 || ws->dec->precision == 2) && !g_split_render; }
+
+// render chain after the forward pass: scan / offsets / scatter, Jacobian pass, per-ray reduce (optimizer.py:93-132)
+int render_back(hm_workspace_s* ws, const RenderCfg& rc, const RenderBuffers& rb, const hm_batch* bt, int P,
+                const int* d_active, hipStream_t st) {
+  const int B = bt->B;
+  int rc_ = launch_render_scan(rc, rb, d_active, B, st);
+  if (rc_) return rc_;
+  if (fused_path(ws))
+    rc_ = launch_decoder_h_bwd(ws->dec, B, d_active, ws->c0, ws->c4, ws->ldJ, rb.ptsG, rb.nG, ws->nG_stride, rb.JG, P,
+                               rb.srcG, rb.sdfR, rb.maskR, ws->nR_stride, st);
+  else
+    rc_ = launch_decoder(ws->dec, B, rb.ptsG, rb.nG, d_active, ws->nG_stride, ws->c0, ws->c4, rb.yG, rb.JG, ws->ldJ, P, 1, st, 1);
+  if (rc_) return rc_;
+  return launch_render_reduce(rc, rb, d_active, B, ws->L, st);
+}
+
+// render front end + forward pass + the above, for the current state (the functional render API)
 int render_pass(hm_workspace_s* ws, const RenderCfg& rc, const RenderBuffers& rb, const hm_batch* bt, int P,
                 const int* d_active, hipStream_t st, const float* d_frame_override = nullptr) {
   const int B = bt->B;
   int rc_ = launch_render_front(rc, rb, bt->d_T_ow, d_active, B, st, d_frame_override);
   if (rc_) return rc_;
-  rc_ = launch_decoder(ws->dec, B, rb.ptsRc, rb.nRq, d_active, ws->nR_stride, ws->c0, ws->c4, rb.sdfR, nullptr, 0, 0, 0, st);
+  if (fused_path(ws))
+    rc_ = launch_decoder_h_fwd_masks(ws->dec, B, d_active, ws->c0, ws->c4, rb.ptsRc, rb.nRq, ws->nR_stride, rb.sdfR,
+                                     rb.maskR, st);
+  else
+    rc_ = launch_decoder(ws->dec, B, rb.ptsRc, rb.nRq, d_active, ws->nR_stride, ws->c0, ws->c4, rb.sdfR, nullptr, 0, 0, 0, st);
   if (rc_) return rc_;
-  rc_ = launch_render_scan(rc, rb, d_active, B, st);
-  if (rc_) return rc_;
-  rc_ = launch_decoder(ws->dec, B, rb.ptsG, rb.nG, d_active, ws->nG_stride, ws->c0, ws->c4, rb.yG, rb.JG, ws->ldJ, P, 1, st, 1);
-  if (rc_) return rc_;
-  return launch_render_reduce(rc, rb, d_active, B, ws->L, st);
+  return render_back(ws, rc, rb, bt, P, d_active, st);
 }
 
 }  // namespace
@@ -239,6 +265,8 @@ int render_pass(hm_workspace_s* ws, const RenderCfg& rc, const RenderBuffers& rb
 // A debug entry point, not an environment variable read on the product path.
 static int g_force_direct = 0;
 extern "C" void hm_debug_force_direct_solve(int on) { g_force_direct = on ? 1 : 0; }
+// A/B hook: 1 = the round-2 launch sequence of the f16x3 render chain (see g_split_render)
+extern "C" void hm_debug_split_render(int on) { g_split_render = on ? 1 : 0; }
 
 extern "C" int hm_workspace_create(hm_decoder_s* dec, const hm_limits* lim, hm_workspace_s** out) {
   if (dec == nullptr || lim == nullptr || out == nullptr) { hm_set_error("null argument"); return -1; }
@@ -383,8 +411,10 @@ extern "C" int hm_optimize_batch(hm_workspace_s* ws, const hm_opt_cfg* cfg, cons
     }
     rc = launch_latent_bias(ws->dec, bt->d_latent, L, ws->active, B, ws->c0, ws->c4, st);
     if (rc) return rc;
+    const bool fused = mode == 0 && fused_path(ws);
     if (mode == 0) {
-      rc = render_pass(ws, rcfg, rb, bt, P, ws->active, st);
+      if (fused) rc = launch_render_front(rcfg, rb, bt->d_T_ow, ws->active, B, st);
+      else rc = render_pass(ws, rcfg, rb, bt, P, ws->active, st);
       if (rc) return rc;
     }
     rc = launch_transform_points(bt->d_points_w, bt->points_stride, bt->d_n_points, bt->d_T_ow, ws->active, B,
@@ -401,10 +431,18 @@ extern "C" int hm_optimize_batch(hm_workspace_s* ws, const hm_opt_cfg* cfg, cons
       ws->ev_used += 2;
       HM_CHECK_HIP(hipEventRecord(ev0, st));
     }
-    rc = launch_decoder(ws->dec, B, ws->ptsS, bt->d_n_points, ws->active, ws->nS_stride, ws->c0, ws->c4, ws->yS,
-                        ws->JS, ws->ldJ, P == 0 ? 6 : P, 1, st, 0);
+    if (fused)     // ONE grid: SDF-term forward+backward tiles, then the forward-only tiles of the ray samples
+      rc = launch_decoder_h_main(ws->dec, B, ws->active, ws->c0, ws->c4, ws->ldJ, ws->ptsS, bt->d_n_points, ws->nS_stride,
+                                 ws->yS, ws->JS, P, rb.ptsRc, rb.nRq, ws->nR_stride, rb.sdfR, rb.maskR, st);
+    else
+      rc = launch_decoder(ws->dec, B, ws->ptsS, bt->d_n_points, ws->active, ws->nS_stride, ws->c0, ws->c4, ws->yS,
+                          ws->JS, ws->ldJ, P == 0 ? 6 : P, 1, st, 0);
     if (rc) return rc;
     if (ev1) HM_CHECK_HIP(hipEventRecord(ev1, st));
+    if (fused) {
+      rc = render_back(ws, rcfg, rb, bt, P, ws->active, st);
+      if (rc) return rc;
+    }
 
     const bool robust = it >= cfg->robust_iter;                             // optimizer.py:145,183
     RowSegment segs[3];

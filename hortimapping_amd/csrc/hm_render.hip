@@ -296,6 +296,7 @@ __global__ __launch_bounds__(256) void k_ray_scatter(const RenderCfg cfg, const 
   f32x4 p = reinterpret_cast<const f32x4*>(rb.ptsR)[src];
   p[3] = 1.f;
   reinterpret_cast<f32x4*>(rb.ptsG)[(size_t)b * rb.nG_stride + dst] = p;
+  rb.srcG[(size_t)b * rb.nG_stride + dst] = rb.cpos[src];       // where the forward pass decoded this sample
   rb.coefG[((size_t)b * rb.nG_stride + dst) * 2 + 0] = rb.coef[src * 2 + 0];
   rb.coefG[((size_t)b * rb.nG_stride + dst) * 2 + 1] = rb.coef[src * 2 + 1];
 }

@@ -35,16 +35,24 @@ def c2_opt_cfg(max_iter=200, n_sample_on_ray=16, n_frame=1):
 
 
 # The WELL-CONDITIONED full-size case: same sizes as C2 (L = 256, 8 x 512 decoder, 200 forced
-# iterations, free Sim(3) pose), but a 4-frame render block that observes the pose (4 x 128 rays x 16 samples, 8 cm camera
-# baseline), the render terms weighted 10 x lower and the LM damping of lab_berry.yaml (lm_lambda_0 = 1.0): under these
-# user-settable YAML values the reference's own 200-iteration result moves by ~1e-5 (not 1e-2) under a one-ulp input
-# change, so BASELINE.json's "within 1e-4 relative" can be tested outright, without a noise clause.
+# iterations, free Sim(3) pose), chosen by MEASURING the reference algorithm's own response to one-ulp input changes
+# (scripts/find_wellconditioned.py; profiles/r03_wc_search*.txt) until BASELINE.json's "within 1e-4 relative" can be
+# tested outright: a more elongated fruit (decoder anisotropy 0.6 : 1 : 2, so that the rotation is observable -- on the
+# bench's 1 : 0.75 : 1.3 fruit the rotation error alone moves by more than 1e-4 of itself), a 4-frame render block
+# (4 x 128 rays x 16 samples, 8 cm camera baseline), the render terms weighted 10 x lower (their hard sample-set switches
+# are what makes the C2 iteration chaotic), lm_lambda_0 = 1.0 (the value of lab_berry.yaml) and w_codereg = 1e-2.  All of
+# these are user-settable YAML values of the reference's config schema.
+WC_DECODER_KW = dict(seed=2, r0=0.04, aniso=(0.6, 1.0, 2.0))
 WC_INSTANCE_KW = dict(n_pts=1024, n_frames=4, n_fg=64, n_bg=64, baseline=0.08)
+
+
+def wc_decoder_params(latent_dim=256):
+    return S.make_synthetic_decoder(latent_dim, **WC_DECODER_KW)
 
 
 def wc_opt_cfg(max_iter=200):
     o = c2_opt_cfg(max_iter=max_iter, n_sample_on_ray=16, n_frame=4)
-    o["weight"].update(w_depth=5e-3, w_mask=5e-5)
+    o["weight"].update(w_depth=5e-3, w_mask=5e-5, w_codereg=1e-2)
     o["lm"]["lm_lambda_0"] = 1.0
     return o
 

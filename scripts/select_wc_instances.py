@@ -24,7 +24,7 @@ def main():
     sys.argv = argv
     from hortimapping_amd import metrics as MX, optimizer as HO, synthetic as S, workloads as W
     from hortimapping_amd.decoder import DecoderWeights
-    params = S.make_synthetic_decoder(256, seed=2, r0=0.04, aniso=(1.0, 0.75, 1.3))
+    params = W.wc_decoder_params(256)
     dec = DecoderWeights.from_params(params)
     dec.set_precision(precision)
     sampler = DecoderWeights.from_params(params)

@@ -37,7 +37,7 @@ MODES = ("known", "free")
 CASES = {
     # case -> (inputs fixture, output fixture, cfg keyword arguments of workloads.c2_opt_cfg)
     "c2": ("c2_fullsize_inputs.npz", "c2_fullsize_reference.npz", dict()),
-    "wc": ("wc_fullsize_inputs.npz", "wc_fullsize_reference.npz", dict(n_frame=4)),
+    "wc": ("wc_fullsize_inputs.npz", "wc_fullsize_reference.npz", dict()),
 }
 
 
@@ -76,13 +76,14 @@ def _run(task):
         from oracle import ref_shim
         from hortimapping_amd import synthetic as S
         ns = ref_shim.import_reference()
-        p = S.make_synthetic_decoder(L, seed=2, r0=0.04, aniso=(1.0, 0.75, 1.3))
+        from hortimapping_amd import workloads as W0
+        p = W0.wc_decoder_params(L) if case == "wc" else S.make_synthetic_decoder(L, seed=2, r0=0.04, aniso=(1.0, 0.75, 1.3))
         _REF = (ns, ref_shim.build_reference_decoder(ns, p), _perturb())
     ns, dec, perturb = _REF
     from hortimapping_amd import workloads as W
     inp = np.load(os.path.join(HERE, CASES[case][0]))
     d = perturb(load_instance(inp, i), pert)
-    cfg = {"device": "cpu", "opt": W.c2_opt_cfg(max_iter=n_iter, **CASES[case][2]),
+    cfg = {"device": "cpu", "opt": (W.wc_opt_cfg(max_iter=n_iter) if case == "wc" else W.c2_opt_cfg(max_iter=n_iter)),
            "vis": {"vis_pause_s": 0, "log_on": False, "vis_on": False}}
     opt = ns.optimizer.Optimizer(cfg, dec, None, None)
     t = torch.from_numpy
@@ -115,8 +116,12 @@ def main():
     ap.add_argument("--case", default="c2", choices=sorted(CASES))
     ap.add_argument("--scratch", default="/tmp/c2_reference_records")
     ap.add_argument("--assemble-only", action="store_true")
+    ap.add_argument("--modes", default="known,free")
+    ap.add_argument("--perts", default=",".join(PERTS))
     a = ap.parse_args()
-    ids = parse_ids(a.instances)
+    global MODES, PERTS
+    MODES, PERTS = tuple(a.modes.split(",")), tuple(a.perts.split(","))
+    ids = parse_ids(a.instances)                     # positions in the inputs fixture
     os.makedirs(a.scratch, exist_ok=True)
     tasks = [(a.case, i, m, p, a.iters, a.scratch) for i in ids for p in PERTS for m in MODES]
     if not a.assemble_only:

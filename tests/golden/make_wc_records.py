@@ -37,8 +37,8 @@ KEYS_F = ("T_wc", "rays_fg", "rays_bg", "depth_fg", "depth_bg")
 
 
 def decoder_params():
-    from hortimapping_amd import synthetic as S
-    return S.make_synthetic_decoder(L, seed=2, r0=0.04, aniso=(1.0, 0.75, 1.3))
+    from hortimapping_amd import workloads as W
+    return W.wc_decoder_params(L)
 
 
 def _gen(i):
@@ -106,7 +106,10 @@ def main():
     elif stage == "records":
         n_keep = int(sys.argv[2]) if len(sys.argv) > 2 else 24
         n_iter = int(sys.argv[3]) if len(sys.argv) > 3 else 200
-        sel = json.load(open(os.path.join(ROOT, "gpurun_out", "wc_selection.json")))
+        sel_path = os.path.join(HERE, "wc_selection.json")          # committed copy of the GPU box's gpurun_out/wc_selection.json
+        if not os.path.exists(sel_path):
+            sel_path = os.path.join(ROOT, "gpurun_out", "wc_selection.json")
+        sel = json.load(open(sel_path))
         cand = np.load(os.path.join(HERE, "wc_candidates.npz"))
         order = sorted(range(len(sel["score"])), key=lambda i: sel["score"][i])[:n_keep]
         keep = sorted(order)

@@ -365,8 +365,8 @@ def test_trained_short_horizon_parity(mode, precision):
 # ----------------------------------------------------------------------------------------------------------------
 def test_wellconditioned_free_pose_parity(precision):
     """Same sizes as the bench (L = 256, 8 x 512 decoder, 200 forced LM iterations) with a FREE Sim(3) pose, on a case
-    where the reference algorithm itself is stable: `workloads.wc_opt_cfg` (4 frames x 128 rays x 16 samples, render terms
-    weighted 10 x lower, lm_lambda_0 = 1.0 as in lab_berry.yaml) on the instances `tests/golden/make_wc_records.py` kept
+    where the reference algorithm itself is stable: `workloads.wc_opt_cfg` / `wc_decoder_params` (an elongated fruit, 4 frames
+    x 128 rays x 16 samples, render terms weighted 10 x lower, lm_lambda_0 = 1.0 as in lab_berry.yaml, w_codereg = 1e-2) on the instances `tests/golden/make_wc_records.py` kept
     (the candidates whose OWN response to 16 one-ulp input perturbations uses the smallest fraction of the tolerance; the
     stored CPU-oracle records repeat that measurement with four perturbations and it is asserted below).  Gate, for
     EVERY instance and the two fp32-class arithmetics:
@@ -381,7 +381,7 @@ def test_wellconditioned_free_pose_parity(precision):
     n = inp["latent0"].shape[0]
     n_iter = int(rec["n_iter"])
     assert n >= 16 and n_iter == 200 and np.all(rec["free_iter_count"] == 200)
-    params = S.make_synthetic_decoder(L, seed=2, r0=0.04, aniso=(1.0, 0.75, 1.3))
+    params = W.wc_decoder_params(L)
     sampler = DecoderWeights.from_params(params)
     sampler.set_precision("f32")
     gt = MX.ground_truth_points_world(sampler, inp["z_true"], inp["T_wo_true"])
