@@ -6,7 +6,9 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libhortihip.so")
+# HORTIHIP_LIB: development aid for same-box A/B timing of kernel variants (scripts/build_variant.sh builds them under
+# build/); unset = the in-tree library.  Either way a missing file is an error, never a fallback.
+LIB_PATH = os.environ.get("HORTIHIP_LIB") or os.path.join(_HERE, "libhortihip.so")
 _lib = None
 
 c_float_p = ctypes.POINTER(ctypes.c_float)

@@ -108,6 +108,7 @@ def parse_ids(s):
 
 
 def main():
+    global MODES, PERTS
     import multiprocessing as mp
     ap = argparse.ArgumentParser()
     ap.add_argument("--instances", default="0-7")
@@ -117,9 +118,8 @@ def main():
     ap.add_argument("--scratch", default="/tmp/c2_reference_records")
     ap.add_argument("--assemble-only", action="store_true")
     ap.add_argument("--modes", default="known,free")
-    ap.add_argument("--perts", default=",".join(PERTS))
+    ap.add_argument("--perts", default="nominal,points_up,points_down,pose0_up,depth_up")
     a = ap.parse_args()
-    global MODES, PERTS
     MODES, PERTS = tuple(a.modes.split(",")), tuple(a.perts.split(","))
     ids = parse_ids(a.instances)                     # positions in the inputs fixture
     os.makedirs(a.scratch, exist_ok=True)
