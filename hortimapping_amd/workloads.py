@@ -40,8 +40,11 @@ def c2_opt_cfg(max_iter=200, n_sample_on_ray=16, n_frame=1):
 # tested outright: a more elongated fruit (decoder anisotropy 0.6 : 1 : 2, so that the rotation is observable -- on the
 # bench's 1 : 0.75 : 1.3 fruit the rotation error alone moves by more than 1e-4 of itself), a 4-frame render block
 # (4 x 128 rays x 16 samples, 8 cm camera baseline), the render terms weighted 10 x lower (their hard sample-set switches
-# are what makes the C2 iteration chaotic), lm_lambda_0 = 1.0 (the value of lab_berry.yaml) and w_codereg = 1e-2.  All of
-# these are user-settable YAML values of the reference's config schema.
+# are what makes the C2 iteration chaotic) and lm_lambda_0 = 1.0 (the value of lab_berry.yaml); the code regulariser keeps
+# wild_pepper's 5e-4, so the latent moves as far as in C2 (a stronger one would be more stable still but pins the latent at
+# zero).  All of these are user-settable YAML values of the reference's config schema.  Even so only about one candidate
+# instance in six is stable to a third of the tolerance in ALL four metrics (the rotation error is the sensitive one):
+# the fixture keeps those (scripts/select_wc_instances.py, tests/golden/wc_selection.json).
 WC_DECODER_KW = dict(seed=2, r0=0.04, aniso=(0.6, 1.0, 2.0))
 WC_INSTANCE_KW = dict(n_pts=1024, n_frames=4, n_fg=64, n_bg=64, baseline=0.08)
 
@@ -52,7 +55,7 @@ def wc_decoder_params(latent_dim=256):
 
 def wc_opt_cfg(max_iter=200):
     o = c2_opt_cfg(max_iter=max_iter, n_sample_on_ray=16, n_frame=4)
-    o["weight"].update(w_depth=5e-3, w_mask=5e-5, w_codereg=1e-2)
+    o["weight"].update(w_depth=5e-3, w_mask=5e-5)
     o["lm"]["lm_lambda_0"] = 1.0
     return o
 

@@ -24,3 +24,4 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE S
 done
 tail -1 $out/${tag}_bench_under_rocprof.log | cut -c1-300
 ls -la $out | grep $tag
+python scripts/make_traffic_json.py $out $tag $out/${tag%%_*}_traffic.json

@@ -71,6 +71,9 @@ CANDIDATES["x_creg1"] = _B128 + (dict(_WL, **{"weight.w_codereg": 1e-1}),)
 CANDIDATES["x_an"] = _B128 + (_WL, dict(aniso=(0.7, 1.0, 1.6)))
 CANDIDATES["x_an_creg2"] = _B128 + (dict(_WL, **{"weight.w_codereg": 1e-2}), dict(aniso=(0.7, 1.0, 1.6)))
 CANDIDATES["x_an2_creg2"] = _B128 + (dict(_WL, **{"weight.w_codereg": 1e-2}), dict(aniso=(0.6, 1.0, 2.0)))
+CANDIDATES["x_an2"] = _B128 + (_WL, dict(aniso=(0.6, 1.0, 2.0)))
+CANDIDATES["x_an2_creg3"] = _B128 + (dict(_WL, **{"weight.w_codereg": 2e-3}), dict(aniso=(0.6, 1.0, 2.0)))
+CANDIDATES["x_an3"] = _B128 + (_WL, dict(aniso=(0.5, 1.0, 2.5)))
 CANDIDATES["x_creg2_se3"] = _B128 + (dict(_WL, **{"weight.w_codereg": 1e-2, "scale_on": False}),)
 CANDIDATES["x_creg2_b16"] = (dict(n_pts=1024, n_frames=4, n_fg=64, n_bg=64, baseline=0.16), dict(n_sample_on_ray=16, n_frame=4),
                              dict(_WL, **{"weight.w_codereg": 1e-2}))
@@ -157,7 +160,7 @@ def main():
             print(f"   fraction of the 1e-4 tolerance used by the noise, per metric (CD, t, r, s): median {np.round(np.median(frac, 0), 2).tolist()} "
                   f"p90 {np.round(np.percentile(frac, 90, axis=0), 2).tolist()}; instances with all four <= 0.3: {(frac.max(1) <= 0.3).sum()}, "
                   f"<= 0.5: {(frac.max(1) <= 0.5).sum()}, <= 1: {(frac.max(1) <= 1).sum()}; nominal medians t_err {1e3 * np.median(m[0][:, 1]):.2f} mm "
-                  f"r_err {np.median(m[0][:, 2]):.2f} deg", flush=True)
+                  f"r_err {np.median(m[0][:, 2]):.2f} deg; final |latent| median {np.median([float(r.latent.abs().max()) for r in res]):.1e}", flush=True)
             if os.environ.get("WC_DUMP"):
                 print("   rel CD noise per instance:", " ".join(f"{v:.1e}" for v in rel), flush=True)
 

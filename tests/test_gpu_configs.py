@@ -252,7 +252,7 @@ def test_frame_turns_invalid_mid_trajectory_L256(precision):
                 assert (int(c[0]), int(c[1]), int(c[2])) == (tr[k - 1].n_valid, tr[k - 1].n_keep, tr[k - 1].n_rays), (d["id"], k, c)
             states[k] = r
         assert states[8].status & 64                                   # FRAME_SKIPPED (informational)
-        for k in ((2, 8) if d["id"] == 4 else (2,)):
+        for k in ((2, 8) if (d["id"] == 4 and precision in ("f32", "f16x3")) else (2,)):
             opt = W.c2_opt_cfg(max_iter=k, n_sample_on_ray=16, n_frame=2)
             z, T, n = O.shape_pose_joint_opt(od, opt, torch.from_numpy(d["latent0"]), torch.from_numpy(d["T_ow0"]), rd,
                                              torch.from_numpy(d["points_w"]), d["cube_radius"], pose_known=False)
