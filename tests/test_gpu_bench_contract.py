@@ -120,3 +120,31 @@ def test_bench_two_ranks_real_job_on_one_gpu():
     a = torch.load(os.path.join(ROOT, "gpurun_out", "tmp_records_2rank.pt"))
     b = torch.load(os.path.join(ROOT, "gpurun_out", "tmp_records_1rank.pt"))
     assert a.shape == b.shape == (8, 32 + 18) and torch.equal(a, b)          # same instances, same order, same bits
+
+
+def test_bench_started_bare_spawns_ranks_that_run_the_real_job():
+    """`python bench.py --gpus 2` with no launcher and no rank environment (how the driver starts the N = 1 bench, with a
+    larger N): bench.py re-executes itself under torch.distributed.run.  Here the two ranks share this box's one GPU
+    (`--share-gpu`, collectives over gloo; on a multi-GPU node the same path runs RCCL, tests/test_gpu_rccl.py); the
+    gathered records must equal the one-rank run bit for bit and exactly one JSON line may come out."""
+    import torch
+    out_dir = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(out_dir, exist_ok=True)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "TORCHELASTIC_RUN_ID",
+                                                              "MASTER_ADDR", "MASTER_PORT")}
+    common = ["--steps", "1", "--warmup", "0", "--latent", "32", "--iters", "5", "--no-exact", "--no-cpu-baseline"]
+    two = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-gpu", "--batch", "4",
+                          "--dump-records", os.path.join(out_dir, "tmp_records_bare2.pt")] + common, env=env,
+                         capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert two.returncode == 0, two.stdout[-1500:] + two.stderr[-1500:]
+    lines = [l for l in two.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["collective_backend"] == "gloo" and "test_mode" in d
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--batch", "8", "--dump-records",
+                          os.path.join(out_dir, "tmp_records_bare1.pt")] + common, env=env, capture_output=True, text=True,
+                         timeout=900, cwd=ROOT)
+    assert one.returncode == 0, one.stderr[-1500:]
+    a = torch.load(os.path.join(out_dir, "tmp_records_bare2.pt"))
+    b = torch.load(os.path.join(out_dir, "tmp_records_bare1.pt"))
+    assert a.shape == b.shape == (8, 32 + 18) and torch.equal(a, b)
