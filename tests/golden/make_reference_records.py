@@ -38,6 +38,8 @@ CASES = {
     # case -> (inputs fixture, output fixture, cfg keyword arguments of workloads.c2_opt_cfg)
     "c2": ("c2_fullsize_inputs.npz", "c2_fullsize_reference.npz", dict()),
     "wc": ("wc_fullsize_inputs.npz", "wc_fullsize_reference.npz", dict()),
+    # the C2 workload on the TRAINED decoder (dense layers; tests/golden/trained_decoder_L256.npz)
+    "trained": ("trained_c2_inputs.npz", "trained_c2_reference.npz", dict()),
 }
 
 
@@ -77,7 +79,11 @@ def _run(task):
         from hortimapping_amd import synthetic as S
         ns = ref_shim.import_reference()
         from hortimapping_amd import workloads as W0
-        p = W0.wc_decoder_params(L) if case == "wc" else S.make_synthetic_decoder(L, seed=2, r0=0.04, aniso=(1.0, 0.75, 1.3))
+        if case == "trained":
+            with np.load(os.path.join(HERE, "trained_decoder_L256.npz")) as f:
+                p = {k: (int(f[k]) if k in ("latent_dim", "hidden") else f[k]) for k in f.files if k.startswith("lin") or k in ("latent_dim", "hidden")}
+        else:
+            p = W0.wc_decoder_params(L) if case == "wc" else S.make_synthetic_decoder(L, seed=2, r0=0.04, aniso=(1.0, 0.75, 1.3))
         _REF = (ns, ref_shim.build_reference_decoder(ns, p), _perturb())
     ns, dec, perturb = _REF
     from hortimapping_amd import workloads as W

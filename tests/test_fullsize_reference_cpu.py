@@ -23,10 +23,10 @@ L = 256
 N_CD = 3                      # instances whose Chamfer distance is sampled on the CPU (the decoder forward is the cost)
 
 
-def _load():
-    ref = np.load(os.path.join(GOLDEN_DIR, "c2_fullsize_reference.npz"))
-    orc = np.load(os.path.join(GOLDEN_DIR, "c2_fullsize_oracle.npz"))
-    inp = np.load(os.path.join(GOLDEN_DIR, "c2_fullsize_inputs.npz"))
+def _load(prefix="c2_fullsize"):
+    ref = np.load(os.path.join(GOLDEN_DIR, prefix + "_reference.npz"))
+    orc = np.load(os.path.join(GOLDEN_DIR, prefix + "_oracle.npz"))
+    inp = np.load(os.path.join(GOLDEN_DIR, prefix + "_inputs.npz"))
     ids = ref["inst_ids"]
     assert list(ref["perts"]) == list(orc["perts"][:len(ref["perts"])])      # same perturbations, same order
     return ref, orc, inp, ids
@@ -49,10 +49,12 @@ def _state_dev(a, b):
     return np.abs(a[0] - b[0]).reshape(a[0].shape[0], -1).max(axis=1), np.abs(a[1] - b[1]).reshape(a[1].shape[0], -1).max(axis=1)
 
 
-def test_oracle_deviates_from_reference_like_one_more_perturbed_run_state_level():
-    """(a) at state level, all instances x both modes: rank of |oracle_nominal - reference_nominal| among the four
-    |reference_pert - reference_nominal|; and (b) noise levels within 2x."""
-    ref, orc, inp, ids = _load()
+@pytest.mark.parametrize("prefix", ["c2_fullsize", "trained_c2"])
+def test_oracle_deviates_from_reference_like_one_more_perturbed_run_state_level(prefix):
+    """(a) at state level, all instances x both modes: rank of |oracle_nominal - reference_nominal| among the K
+    |reference_pert - reference_nominal| (K = 4 on the analytic decoder, 16 instances; K = 2 on the TRAINED decoder with
+    its dense, kinked layers, 6 instances); and (b) noise levels within 2x (analytic) / 3x (trained, 2 draws each)."""
+    ref, orc, inp, ids = _load(prefix)
     us, ratios = [], []
     for m in ("known", "free"):
         zr, Tr = ref[f"{m}_latent"], ref[f"{m}_T_ow"]
@@ -68,13 +70,15 @@ def test_oracle_deviates_from_reference_like_one_more_perturbed_run_state_level(
             ratios.append(np.log(pert_o.max(axis=0) / pert_r.max(axis=0)))
             # (no per-instance cap: the largest of FOUR heavy-tailed draws is too coarse a yardstick for a fifth)
     u = np.concatenate(us)
-    dplus, p = PS.ks_upper(u, 4)
-    print(f"\nstate-level ranks of |oracle - reference| among the reference's 4 perturbed runs: n={len(u)} mean {u.mean():.2f} "
-          f"KS+ {dplus:.3f} p {p:.3f}")
-    assert p >= 1e-3 and u.mean() < 0.75
+    K = ref["known_latent"].shape[0] - 1
+    dplus, p = PS.ks_upper(u, K)
+    print(f"\n{prefix}: state-level ranks of |oracle - reference| among the reference's {K} perturbed runs: n={len(u)} mean "
+          f"{u.mean():.2f} KS+ {dplus:.3f} p {p:.3f}")
+    assert p >= 1e-3 and u.mean() < 0.8
     g = float(np.exp(np.mean(np.concatenate(ratios))))
-    print(f"oracle noise / reference noise (geometric mean over instances, modes, latent and pose): {g:.2f}")
-    assert 0.5 <= g <= 2.0
+    print(f"{prefix}: oracle noise / reference noise (geometric mean over instances, modes, latent and pose): {g:.2f}")
+    lim = 2.0 if K >= 4 else 3.0
+    assert 1.0 / lim <= g <= lim
 
 
 def _cpu_metrics(od, lat, T_ow, gt_world, T_wo_true, dirs):
