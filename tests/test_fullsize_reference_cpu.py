@@ -173,3 +173,20 @@ def test_wellconditioned_case_oracle_equals_reference():
     moved = np.abs(zo[0] - inp["latent0"]).max(axis=1)
     assert np.all(moved > 100 * np.abs(zo[1:] - zo[0]).max(axis=(0, 2)))                 # the optimisation did move the latent
     assert np.median(np.linalg.norm(zo[0], axis=1)) > 3e-3                               # ... comparably to C2 (1.8e-2 free pose)
+
+
+def test_shape_only_loop_oracle_equals_reference_at_state_level():
+    """`shape_opt_deepsdf` (optimizer.py:306-429; bench.py's `c2_sdf`) at L = 256 after 200 forced iterations is WELL
+    conditioned: the oracle reproduces the ACTUAL reference's latent to fp32 rounding (measured <= 1e-6 of its size), the
+    response of both to a one-ulp scaling of the points is the same smooth 1e-5, and a perturbation of an input this loop
+    does not read (foreground depths) reproduces the nominal run bit for bit.  tests/golden/make_sdf_records.py."""
+    r = np.load(os.path.join(GOLDEN_DIR, "c2_sdf_fullsize_records.npz"))
+    zr, zo = r["ref_latent"], r["orc_latent"]
+    n = zr.shape[1]
+    sc = np.abs(zo[0]).max(axis=1)
+    assert np.all(np.abs(zo[0][:n] - zr[0]).max(axis=1) <= 5e-6 * sc[:n])
+    noise_r = np.abs(zr[1:] - zr[0]).max(axis=(0, 2)) / sc[:n]
+    noise_o = np.abs(zo[1:3] - zo[0]).max(axis=(0, 2)) / sc
+    assert np.all(noise_r <= 1e-4) and np.all(np.abs(noise_o[:n] / noise_r - 1.0) < 0.1)     # the same smooth response
+    assert list(r["orc_perts"][3:]) == ["pose0_up", "depth_up"] and np.array_equal(zo[4], zo[0])
+    assert np.all(sc > 5e-3)                                                                  # the latent moved

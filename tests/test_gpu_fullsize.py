@@ -433,3 +433,38 @@ def test_wellconditioned_free_pose_parity(precision):
     if precision in ("f32", "f16x3"):
         assert np.all(dev <= tol), [(int(inp["inst_ids"][i]), (dev[i] / tol[i]).round(2).tolist()) for i in range(n) if np.any(dev[i] > tol[i])]
         assert np.all(d_gr <= tol[pos])
+
+
+def test_shape_only_fullsize_state_parity(precision):
+    """The shape-only loop (`shape_opt_deepsdf`, bench.py's `c2_sdf` line) at full size -- L = 256, 200 forced iterations,
+    16 instances of the C2 fixture (their 1024 surface points) -- is well conditioned, so parity is asserted at STATE level
+    and outright: the HIP latent against the CPU oracle AND against the records of the ACTUAL reference loop
+    (tests/golden/c2_sdf_fullsize_records.npz: oracle == reference to 1e-6 there), to 2e-5 of the latent's size in the two
+    fp32-class arithmetics; the pose must come back untouched."""
+    import os
+    from golden_util import GOLDEN_DIR
+    from hortimapping_amd import optimizer as HO, workloads as W
+    from hortimapping_amd.decoder import DecoderWeights
+    fs = fullsize_fixture("analytic")
+    rec = np.load(os.path.join(GOLDEN_DIR, "c2_sdf_fullsize_records.npz"))
+    zo, zr = rec["orc_latent"][0], rec["ref_latent"][0]
+    n = zo.shape[0]
+    dec = DecoderWeights.from_params(fs["params"])
+    dec.set_precision(precision)
+    insts = fullsize_instances(False, "analytic")[:n]
+    res = HO.optimize_batch(dec, W.c2_opt_cfg(max_iter=200), insts, shape_only=True)
+    assert all(r.iter_count == 200 and r.status == 8 for r in res)
+    z = np.stack([r.latent.numpy() for r in res])
+    sc = np.abs(zo).max(axis=1)
+    d_o = np.abs(z - zo).max(axis=1) / sc
+    d_r = np.abs(z[:zr.shape[0]] - zr).max(axis=1) / sc[:zr.shape[0]]
+    print(f"\nshape-only, {precision}: max |z_gpu - z_oracle| / max|z|: median {np.median(d_o):.2e} max {d_o.max():.2e}; vs the reference: max {d_r.max():.2e}")
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open(os.path.join("gpurun_out", f"r03_parity_shape_only_{precision}.txt"), "w") as f:
+        f.write(f"# shape_opt_deepsdf, 16 instances x 200 iterations, L = 256, GPU {precision}: relative latent deviation per instance\n"
+                "# id  vs_oracle  vs_reference(first 8)\n" +
+                "\n".join(f"{i:2d} {d_o[i]:.2e} {(d_r[i] if i < len(d_r) else float('nan')):.2e}" for i in range(n)) + "\n")
+    for inst, r in zip(insts, res):
+        assert torch.equal(r.T_ow, inst.T_ow)
+    if precision in ("f32", "f16x3"):
+        assert d_o.max() < 2e-5 and d_r.max() < 2e-5
