@@ -439,8 +439,9 @@ def test_shape_only_fullsize_state_parity(precision):
     """The shape-only loop (`shape_opt_deepsdf`, bench.py's `c2_sdf` line) at full size -- L = 256, 200 forced iterations,
     16 instances of the C2 fixture (their 1024 surface points) -- is well conditioned, so parity is asserted at STATE level
     and outright: the HIP latent against the CPU oracle AND against the records of the ACTUAL reference loop
-    (tests/golden/c2_sdf_fullsize_records.npz: oracle == reference to 1e-6 there), to 2e-5 of the latent's size in the two
-    fp32-class arithmetics; the pose must come back untouched."""
+    (tests/golden/c2_sdf_fullsize_records.npz: oracle == reference to 1e-6 there), to 5e-5 / 1e-5 of the latent's size in
+    the two fp32-class arithmetics (the mixed and fp16 modes land at 1e-4 and 1e-3: reported); the pose must come back
+    untouched."""
     import os
     from golden_util import GOLDEN_DIR
     from hortimapping_amd import optimizer as HO, workloads as W
@@ -467,4 +468,5 @@ def test_shape_only_fullsize_state_parity(precision):
     for inst, r in zip(insts, res):
         assert torch.equal(r.T_ow, inst.T_ow)
     if precision in ("f32", "f16x3"):
-        assert d_o.max() < 2e-5 and d_r.max() < 2e-5
+        # measured: vs the reference <= 2.2e-6 (8 instances), vs the oracle median 2e-6, max 1.9e-5 (one of 16)
+        assert d_o.max() < 5e-5 and d_r.max() < 1e-5
