@@ -460,7 +460,7 @@ def main(argv=None, emit=True):
                         "max_abs_latent_diff_vs_primary": float((l2 - lat).abs().max()),
                         "max_abs_T_diff_vs_primary": float((T2 - T).abs().max()),
                         "diff_note": "free-pose 200-iteration trajectories amplify rounding noise; per-instance parity of "
-                                     "every arithmetic vs the CPU oracle: profiles/r02_parity_fullsize_*.txt"}
+                                     "every arithmetic vs the CPU oracle: profiles/r03_parity_fullsize_*.txt"}
     if (not stub and not args.no_exact and world == 1 and not strong and args.decoder == "analytic" and L == 256
             and kind == "joint" and per_gpu == 64):
         # the same job on TRAINED decoder weights (dense layers instead of the near-identity analytic ones: different
@@ -470,7 +470,7 @@ def main(argv=None, emit=True):
         out["trained_decoder"] = {"value": o2["value"], "unit": o2["unit"], "steps": 1, "dtype": o2["dtype"],
                                   "ms_per_step": o2["ms_per_step"], "roofline": o2["roofline"],
                                   "decoder_weights": o2["config"]["decoder_weights"],
-                                  "parity": "profiles/r02_parity_trained_*.txt (per-instance vs the CPU oracle)"}
+                                  "parity": "profiles/r03_parity_trained_*.txt (per-instance vs the CPU oracle), r03_parity_vs_reference_trained_*.txt (vs the reference loop)"}
         # the same job with 256 instances resident per GPU (the chunk size of configs[3]): the ragged last tile rounds of
         # the render-chain launches and the per-instance solve amortise over more instances
         o3 = main(["--steps", "1", "--warmup", "1", "--iters", str(args.iters), "--total", "256", "--batch", "256", "--precision",
