@@ -159,7 +159,6 @@ def parse_args(argv=None):
     ap.add_argument("--decoder", default="analytic", choices=["analytic", "trained"],
                     help="decoder weights: the analytic synthetic fruit (default, BASELINE workload) or the weights learnt "
                          "by scripts/train_synthetic_deepsdf.py (tests/golden/trained_decoder_L256.npz, L = 256 only)")
-    ap.add_argument("--stagger", action="store_true", help=argparse.SUPPRESS)        # A/B: the staggered f16x3 kernel (hm_debug_k1h_stagger)
     ap.add_argument("--split-render", action="store_true", help=argparse.SUPPRESS)   # A/B: round-2 launch sequence (hm_debug_split_render)
     ap.add_argument("--stub-cpu", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--share-gpu", action="store_true", help=argparse.SUPPRESS)   # tests: N ranks on ONE GPU over gloo
@@ -267,8 +266,6 @@ def main(argv=None, emit=True):
         lib = _lib.lib()
         if args.split_render:
             lib.hm_debug_split_render(1)
-        if args.stagger:
-            lib.hm_debug_k1h_stagger(1)
         lib.hm_workspace_profile.argtypes = [ctypes.c_void_p, ctypes.c_int]
         lib.hm_workspace_profile_read.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double),
                                                   ctypes.POINTER(ctypes.c_longlong)]

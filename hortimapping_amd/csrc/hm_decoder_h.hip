@@ -13,6 +13,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <type_traits>
+
 #include "hm_common.h"
 #include "hm_internal.h"
 
@@ -56,8 +58,10 @@ struct DecodeArgsH {
   int n_blocks0;         // workgroups of seg[0]; the rest belongs to seg[1]
   DecSeg seg[2];
   long long* trace;    // optional shader-clock stamps of block 0, thread trace_tid (perf analysis), or nullptr:
-                       // k_decoder_h [NSTAGE][4] + 1, k_decoder_hs [NSTAGE][8] + 1
+                       // k_decoder_h [NSTAGE][4] + 1, experimental k_decoder_g [NSTAGE][8] + 1
   int trace_tid;
+  int tune;            // experimental builds (HM_EXPERIMENTAL): bits 0-1 priority scheme of k_decoder_g (0 none, 1 K loops high,
+                       // 2 epilogues high), bit 3 four-set weight ring in k_decoder_h; 0 in the product
 };
 
 constexpr float LO_SCALE = 2048.f;          // 2^11
@@ -142,7 +146,11 @@ __device__ __forceinline__ void load_b(BSet& b, const f16x8* xh, const f16x8* xl
   b.l0 = xl[k * 2 * TQ + xo]; b.l1 = xl[k * 2 * TQ + xo + 32];
 }
 
+#if defined(HM_ABL_NOMFMA)
+#define HM_MFMA(A, B, C) asm volatile("" : "+v"(C) : "v"(A), "v"(B))
+#else
 #define HM_MFMA(A, B, C) C = __builtin_amdgcn_mfma_f32_32x32x16_f16(A, B, C, 0, 0, 0)
+#endif
 #define HM_FENCE() __builtin_amdgcn_sched_barrier(0)
 
 // One K-step with its prefetches woven BETWEEN the MFMAs (pairs of MFMAs, then one or two memory instructions): a
@@ -157,8 +165,16 @@ __device__ __forceinline__ void step_h(f32x16 (&acc)[2][2], const ASet& a, const
   const f16x8* w1 = wp1 + ka * 128;
   const f16x8* ph = xh + kb * 2 * TQ + xo;
   const f16x8* pl = xl + kb * 2 * TQ + xo;
+#if defined(HM_ABL_NOA)          // timing ablations (scripts/build_variant.sh): wrong results
+#define HM_LDA(dst, src)
+#else
 #define HM_LDA(dst, src) dst = src
+#endif
+#if defined(HM_ABL_NOB)
+#define HM_LDB(dst, src)
+#else
 #define HM_LDB(dst, src) dst = src
+#endif
   if (U0 && U1) {
     const f16x8 a0c = a.h0 * cs;
     const f16x8 a1c = a.h1 * cs;
@@ -237,6 +253,10 @@ __device__ __forceinline__ void gemm_loop_h(f32x16 (&acc)[2][2], const f16x8* __
 #undef HM_STEP
 }
 
+
+#ifdef HM_EXPERIMENTAL
+#include "experimental/hm_gemm_loop_h4.inc"
+#endif
 
 // ---- one-pass K loop (precision 2, backward stages only): G W = Gh Wh, a single fp16 MFMA pass on the hi parts.
 // A K-step is 4 MFMAs (128 matrix-pipe cycles per wave) instead of 12, so the weight fetches run THREE steps ahead
@@ -523,15 +543,19 @@ __global__ __launch_bounds__(512, 2) void k_decoder_h(const DecodeArgsH a) {
         else if (u0) gemm_loop_h1<true, false>(acc, wp0, wp1, sh.n_k16, xh, lane);
         else if (u1) gemm_loop_h1<false, true>(acc, wp0, wp1, sh.n_k16, xh, lane);
       } else {
-        if (u0 && u1) gemm_loop_h<true, true>(acc, wp0, wp1, sh.n_k16, xh, xl, lane);
-        else if (u0) gemm_loop_h<true, false>(acc, wp0, wp1, sh.n_k16, xh, xl, lane);
+        if (u0 && u1) {
+#ifdef HM_EXPERIMENTAL
+          if (!BW1 && (a.tune & 8)) gemm_loop_h4<true, true>(acc, wp0, wp1, sh.n_k16, xh, xl, lane);
+          else
+#endif
+          gemm_loop_h<true, true>(acc, wp0, wp1, sh.n_k16, xh, xl, lane);
+        } else if (u0) gemm_loop_h<true, false>(acc, wp0, wp1, sh.n_k16, xh, xl, lane);
         else if (u1) gemm_loop_h<false, true>(acc, wp0, wp1, sh.n_k16, xh, xl, lane);
       }
     }
     if (tr) a.trace[s * 4 + 1] = clock64();
     __syncthreads();
     if (tr) a.trace[s * 4 + 2] = clock64();
-
 
     if (epi <= EPI_FWD7) {
       const float* bias = bl + s * HID;
@@ -716,549 +740,23 @@ __global__ __launch_bounds__(512, 2) void k_decoder_h(const DecodeArgsH a) {
 }
 
 
-// =====================================================================================================================
-// K1hs: the same arithmetic as k_decoder_h<., false>, re-scheduled so that the matrix pipe is not idle during the
-// epilogues (round-2 trace: of a 512 x 512 stage's ~38 k clocks, ~5.8 k sat between two barriers with only VALU / LDS
-// work).  A wave's two 32-row output blocks are no longer accumulated together:
-//   loop A   row block mb0 (= w)      over the whole K        -> acc0
-//   loop B   row block mb1 (= w + 8)  over the whole K        -> acc1, and WOVEN between its MFMAs the epilogue arithmetic
-//                                                                of acc0 (bias / ReLU / mask / hi-lo split), parked packed
-//   barrier B (every wave has read X for the last time), store acc0's packed outputs = rows 0..255 of the next X, barrier C
-// and where the next stage allows it (`pipe`), acc1's epilogue is not done here at all but woven into the FIRST HALF of
-// the next stage's loop A -- which only reads rows 0..255 -- its results stored straight into rows 256..511, followed by
-// barrier D before the second half of that loop.  Per stage: 3 barriers, and the only work outside an MFMA shadow is 16
-// LDS stores per lane.  The B operands (activations) are read from LDS twice, the weights are fetched once as before
-// (measured cost of the split alone: +1.6 %).  Results are bit-identical to k_decoder_h: same products, same order.
-// =====================================================================================================================
-struct A1 { f16x8 h, l; };
-
-// packed epilogue outputs of one 32-row block: chunk c = g * 2 + nb -> 4 values as (hi pair words, lo pair words)
-struct Packed { uint2 hh[8]; uint2 ll[8]; };
-
-__device__ __forceinline__ void split_pack(const f32x2 a, const f32x2 b, bool take_abs, f16x2& xm, uint2& hh, uint2& ll) {
-  const f16x2 ha = __builtin_convertvector(a, f16x2), hb = __builtin_convertvector(b, f16x2);
-  const f32x2 sa = a * LO_SCALE, sb = b * LO_SCALE;
-  uint32_t hau, hbu;
-  __builtin_memcpy(&hau, &ha, 4);
-  __builtin_memcpy(&hbu, &hb, 4);
-  hh = uint2{hau, hbu};
-  ll = uint2{lo_pair(hau, sa[0], sa[1]), lo_pair(hbu, sb[0], sb[1])};
-  track_max(xm, hau, hbu, take_abs);
-}
-
-// forward epilogue arithmetic of chunk C of a block: v = acc * us + bias, ReLU mask bits, ReLU, hi / lo split
-template <int C>
-__device__ __forceinline__ void fwd_chunk(const f32x16 (&ac)[2], const f32x4 (&bv)[4], float us, uint32_t& bits, f16x2& xm,
-                                          uint2& hh, uint2& ll) {
-  constexpr int g = C >> 1, nb = C & 1;
-  const f32x2 us2 = {us, us};
-  const f32x2 b01 = {bv[g][0], bv[g][1]}, b23 = {bv[g][2], bv[g][3]};
-  const f32x2 a01 = {ac[nb][4 * g + 0], ac[nb][4 * g + 1]};
-  const f32x2 a23 = {ac[nb][4 * g + 2], ac[nb][4 * g + 3]};
-  const f32x2 v01 = __builtin_elementwise_fma(a01, us2, b01), v23 = __builtin_elementwise_fma(a23, us2, b23);
-  mask_push(bits, v01[0]); mask_push(bits, v01[1]); mask_push(bits, v23[0]); mask_push(bits, v23[1]);
-  const f32x2 r01 = {fmaxf(v01[0], 0.f), fmaxf(v01[1], 0.f)}, r23 = {fmaxf(v23[0], 0.f), fmaxf(v23[1], 0.f)};
-  split_pack(r01, r23, false, xm, hh, ll);
-}
-
-// backward epilogue arithmetic of chunk C: g = acc * us where the producing layer's ReLU was active, else +0
-template <int C>
-__device__ __forceinline__ void bwd_chunk(const f32x16 (&ac)[2], float us, uint32_t bits, f16x2& xm, uint2& hh, uint2& ll) {
-  constexpr int g = C >> 1, nb = C & 1;
-  const f32x2 us2 = {us, us};
-  const f32x2 p01 = f32x2{ac[nb][4 * g + 0], ac[nb][4 * g + 1]} * us2;
-  const f32x2 p23 = f32x2{ac[nb][4 * g + 2], ac[nb][4 * g + 3]} * us2;
-  const f32x2 v01 = {mask_keep(p01[0], bits, mask_pos(g, nb, 0)), mask_keep(p01[1], bits, mask_pos(g, nb, 1))};
-  const f32x2 v23 = {mask_keep(p23[0], bits, mask_pos(g, nb, 2)), mask_keep(p23[1], bits, mask_pos(g, nb, 3))};
-  split_pack(v01, v23, true, xm, hh, ll);
-}
-
-template <int C>
-__device__ __forceinline__ void store_chunk(f16x4* xh4, f16x4* xl4, int mb, int hi, int qa, const uint2 hh, const uint2 ll) {
-  constexpr int g = C >> 1, nb = C & 1;
-  const int idx = ((mb * 4 + g) * TQ + nb * 32 + qa) * 2 + hi;
-  reinterpret_cast<uint2*>(xh4)[idx] = hh;
-  reinterpret_cast<uint2*>(xl4)[idx] = ll;
-}
-
-template <int I> struct IC { static constexpr int value = I; };
-struct NoWeave { template <int I> __device__ __forceinline__ void operator()(IC<I>) const {} };
-
-// One K-step of ONE row block (6 MFMAs) with its prefetches and one piece of woven VALU work between the MFMA pairs.
-template <class Piece>
-__device__ __forceinline__ void step_r(f32x16 (&ac)[2], const A1& a, const BSet& b, A1& an, BSet& bn,
-                                       const f16x8* __restrict__ wp, int ka, const f16x8* xh, const f16x8* xl, int kb,
-                                       int xo, Piece&& piece) {
-  const _Float16 cs = (_Float16)LO_UNSCALE;
-  const f16x8* w0 = wp + ka * 128;
-  const f16x8* ph = xh + kb * 2 * TQ + xo;
-  const f16x8* pl = xl + kb * 2 * TQ + xo;
-  const f16x8 ac_ = a.h * cs;
-  HM_FENCE();
-  HM_MFMA(a.h, b.h0, ac[0]); HM_MFMA(a.h, b.h1, ac[1]);
-  HM_FENCE(); bn.h0 = ph[0]; bn.h1 = ph[32]; bn.l0 = pl[0]; bn.l1 = pl[32]; HM_FENCE();
-  HM_MFMA(ac_, b.l0, ac[0]); HM_MFMA(ac_, b.l1, ac[1]);
-  HM_FENCE(); an.h = w0[0]; an.l = w0[64]; HM_FENCE();
-  piece();
-  HM_FENCE();
-  HM_MFMA(a.l, b.h0, ac[0]); HM_MFMA(a.l, b.h1, ac[1]);
-  HM_FENCE();
-}
-
-// K loop of one row block over K-steps [k0, k1).  `weave(IC<i>)` is called in the i-th of the first twelve steps
-// (i = 0..11; a no-op functor, or epilogue chunks of another block); needs k1 - k0 >= 12 when WOVEN.  Register rings as in
-// gemm_loop_h: weights two steps ahead (three named sets), activations one step ahead (two sets), groups of six
-// branch-free steps.
-template <bool WOVEN, class Weave>
-__device__ __forceinline__ void gemm_loop_r(f32x16 (&ac)[2], const f16x8* __restrict__ wp, int k0, int k1, const f16x8* xh,
-                                            const f16x8* xl, int lane, Weave&& weave) {
-  const int xo = (lane >> 5) * TQ + (lane & 31);
-  const int last = k1 - 1;
-  A1 a0 = {}, a1 = {}, a2 = {};
-  BSet b0, b1 = {};
-  a0.h = wp[k0 * 128]; a0.l = wp[k0 * 128 + 64];
-  { const int k = k0 + 1 < k1 ? k0 + 1 : last; a1.h = wp[k * 128]; a1.l = wp[k * 128 + 64]; }
-  load_b(b0, xh, xl, k0, xo);
-  int ks = k0;
-#define HM_KA(I) ((ks + (I) + 2 < k1) ? ks + (I) + 2 : last)
-#define HM_KB(I) ((ks + (I) + 1 < k1) ? ks + (I) + 1 : last)
-#define HM_STEPW(AS, BS, ANEXT, BNEXT, I, J) \
-  step_r(ac, AS, BS, ANEXT, BNEXT, wp, HM_KA(I), xh, xl, HM_KB(I), xo, [&]() { weave(IC<J>{}); });
-#define HM_STEPN(AS, BS, ANEXT, BNEXT, I) \
-  if (HM_COND(I)) { step_r(ac, AS, BS, ANEXT, BNEXT, wp, HM_KA(I), xh, xl, HM_KB(I), xo, []() {}); }
-  if (WOVEN) {
-    HM_STEPW(a0, b0, a2, b1, 0, 0)
-    HM_STEPW(a1, b1, a0, b0, 1, 1)
-    HM_STEPW(a2, b0, a1, b1, 2, 2)
-    HM_STEPW(a0, b1, a2, b0, 3, 3)
-    HM_STEPW(a1, b0, a0, b1, 4, 4)
-    HM_STEPW(a2, b1, a1, b0, 5, 5)
-    ks += 6;
-    HM_STEPW(a0, b0, a2, b1, 0, 6)
-    HM_STEPW(a1, b1, a0, b0, 1, 7)
-    HM_STEPW(a2, b0, a1, b1, 2, 8)
-    HM_STEPW(a0, b1, a2, b0, 3, 9)
-    HM_STEPW(a1, b0, a0, b1, 4, 10)
-    HM_STEPW(a2, b1, a1, b0, 5, 11)
-    ks += 6;
-  }
-#define HM_COND(I) true
-  for (; ks + 6 <= k1; ks += 6) {
-    HM_STEPN(a0, b0, a2, b1, 0)
-    HM_STEPN(a1, b1, a0, b0, 1)
-    HM_STEPN(a2, b0, a1, b1, 2)
-    HM_STEPN(a0, b1, a2, b0, 3)
-    HM_STEPN(a1, b0, a0, b1, 4)
-    HM_STEPN(a2, b1, a1, b0, 5)
-  }
-#undef HM_COND
-#define HM_COND(I) (ks + (I) < k1)
-  if (ks < k1) {
-    HM_STEPN(a0, b0, a2, b1, 0)
-    HM_STEPN(a1, b1, a0, b0, 1)
-    HM_STEPN(a2, b0, a1, b1, 2)
-    HM_STEPN(a0, b1, a2, b0, 3)
-    HM_STEPN(a1, b0, a0, b1, 4)
-  }
-#undef HM_COND
-#undef HM_STEPN
-#undef HM_STEPW
-#undef HM_KA
-#undef HM_KB
-}
-
-#define HM_MASK_SETX(v) switch (layer_) { case 0: mk0.x = v; break; case 1: mk1.x = v; break; case 2: mk2.x = v; break; \
-  case 3: mk3.x = v; break; case 4: mk4.x = v; break; case 5: mk5.x = v; break; case 6: mk6.x = v; break; default: mk7.x = v; break; }
-#define HM_MASK_SETY(v) switch (layer_) { case 0: mk0.y = v; break; case 1: mk1.y = v; break; case 2: mk2.y = v; break; \
-  case 3: mk3.y = v; break; case 4: mk4.y = v; break; case 5: mk5.y = v; break; case 6: mk6.y = v; break; default: mk7.y = v; break; }
-
-template <int TAG>
-__global__ __launch_bounds__(512, 2) void k_decoder_hs(const DecodeArgsH a) {
-  __shared__ f16x8 xh[64 * TQ];    // 64 KiB: hi plane  X[k/8][q][8]
-  __shared__ f16x8 xl[64 * TQ];    // 64 KiB: lo plane (scaled by 2^11)
-  __shared__ float sc[2048 + 128];
-  __shared__ float bl[9 * HID];
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int si = blockIdx.x >= (unsigned)a.n_blocks0 ? 1 : 0;
-  const DecSeg& sg = a.seg[si];
-  const int blk = si ? blockIdx.x - a.n_blocks0 : blockIdx.x;
-  const int mode = sg.mode;
-  const int b = blk % a.B;
-  const int tile = blk / a.B;
-  const int q0 = tile * TQ;
-  if (a.active != nullptr && a.active[b] == 0) return;
-  const int nq = sg.n_q[b];
-  if (q0 >= nq) return;
-  const int cnt = (nq - q0 < TQ) ? nq - q0 : TQ;
-
-  const int L = a.dec.L, m = a.dec.m, mb_zx = a.dec.mb_zx;
-  const size_t qbase = (size_t)b * sg.n_stride + q0;
-  const int qa = lane & 31;
-  const int hi = lane >> 5;
-  const f32x4* pts4 = reinterpret_cast<const f32x4*>(sg.pts);
-  f16x4* xh4 = reinterpret_cast<f16x4*>(xh);
-  f16x4* xl4 = reinterpret_cast<f16x4*>(xl);
-  float* Jout = sg.J;
-  const int mb0 = w, mb1 = w + 8;
-
-  uint2 mk0 = {0, 0}, mk1 = {0, 0}, mk2 = {0, 0}, mk3 = {0, 0}, mk4 = {0, 0}, mk5 = {0, 0}, mk6 = {0, 0},
-        mk7 = {0, 0};
-  f32x16 acc0[2], acc1[2];
-  float gx0 = 0.f, gx1 = 0.f, gx2 = 0.f;
-  float y_keep = 0.f;
-  f16x2 xm2 = {(_Float16)0.f, (_Float16)0.f};   // range guard: running max of |hi|, see track_max
-  bl[8 * HID + tid] = a.dec.w8[tid];
-
-  if (mode != 2) {
-    if (tid < TQ) {
-      const f32x4 p = pts4[qbase + tid];
-      const f32x2 zz = {0.f, 0.f};
-      f16x2 untracked = {(_Float16)0.f, (_Float16)0.f};
-      split_store<false>(xh4, xl4, (0 * TQ + tid) * 2 + 0, f32x2{p[0], p[1]}, f32x2{p[2], 0.f}, untracked);
-      split_store<false>(xh4, xl4, (0 * TQ + tid) * 2 + 1, zz, zz, untracked);
-      split_store<false>(xh4, xl4, (1 * TQ + tid) * 2 + 0, zz, zz, untracked);
-      split_store<false>(xh4, xl4, (1 * TQ + tid) * 2 + 1, zz, zz, untracked);
-    }
-    const float* cbias0 = a.c0 + (size_t)b * HID;
-    const float* cbias4 = a.c4 + (size_t)b * HID;
-    for (int i = tid; i < 8 * HID; i += 512) {
-      const StageDesc& sb = a.dec.st[i >> 9];
-      const float* src = sb.inst_bias == 1 ? cbias0 : (sb.inst_bias == 2 ? cbias4 : sb.bias);
-      bl[i] = src[i & (HID - 1)];
-    }
-  } else {
-    const int* slot_p = sg.src_slot + qbase;
-    const int tiles_src = sg.src_stride / TQ;
-    float dy[2] = {0.f, 0.f};
-#pragma unroll
-    for (int nb = 0; nb < 2; ++nb) {
-      const int q = nb * 32 + qa;
-      if (q >= cnt) continue;
-      const int slot = slot_p[q];
-      const float yv = sg.y_in[(size_t)b * sg.src_stride + slot];
-      dy[nb] = 1.f - yv * yv;
-      if (hi == 0 && w == 0) sc[2048 + q] = yv;
-      const int nb_src = (slot >> 5) & 1;
-      const uint2* mp = sg.mask_in + (((size_t)b * tiles_src + (slot >> 6)) * 8) * 512 + (w * 64 + hi * 32 + (slot & 31));
-#define HM_GATHER(M, LAYER)                                                     \
-      { const uint2 v = mp[(LAYER) * 512];                                      \
-        M.x |= mask_nibbles(v.x, nb_src, nb); M.y |= mask_nibbles(v.y, nb_src, nb); }
-      HM_GATHER(mk0, 0) HM_GATHER(mk1, 1) HM_GATHER(mk2, 2) HM_GATHER(mk3, 3)
-      HM_GATHER(mk4, 4) HM_GATHER(mk5, 5) HM_GATHER(mk6, 6) HM_GATHER(mk7, 7)
-#undef HM_GATHER
-    }
-    __syncthreads();
-    y_keep = lane < cnt ? sc[2048 + lane] : 0.f;
-    write_g7<false>(xh4, xl4, bl, mk7, mb0, mb1, hi, qa, dy[0], dy[1], xm2);
-  }
-  __syncthreads();                 // stage-entry invariant: the X rows a stage's first K half reads are visible
-
-  const int s_begin = mode == 2 ? 8 : 0;
-  const int s_end = mode == 0 ? 8 : NSTAGE;
-  bool pend = false;               // acc1 of stage p_s still holds raw sums: its epilogue is woven into this stage's loop A
-  int p_s = 0;
-  uint32_t p_bits0 = 0;            // forward: mask word of the pending stage's block 0 (saved with block 1's once known)
-  for (int s = s_begin; s < s_end; ++s) {
-    const StageDesc& sd = a.dec.st[s];
-    const StageDescH& sh = a.dec.sth[s];
-    const int epi = sd.epi;
-    const int layer_ = sd.layer;
-    const bool u0 = (mb0 >= sd.mb_lo) && (mb0 < sd.mb_hi);
-    const bool u1 = (mb1 >= sd.mb_lo) && (mb1 < sd.mb_hi);
-    const float us = sh.unscale;
-    const int n = sh.n_k16;
-    const bool is_fwd = epi <= EPI_FWD7;
-    const bool tr = a.trace != nullptr && blockIdx.x == 0 && tid == a.trace_tid;
-    if (tr) a.trace[s * 8 + 0] = clock64();
-    // Does block 1's epilogue move into the next stage?  Needs: every wave has both blocks here and a plain epilogue,
-    // and the next stage reads its K in two halves of 16 steps that every wave's loop A walks, with no prologue that
-    // needs the whole X at its entry.  (Wave-uniform AND workgroup-uniform: only stage descriptors enter.)
-    bool pipe_out = false;
-    if (s + 1 < s_end && sd.mb_lo == 0 && sd.mb_hi == 16 && (epi == EPI_FWD || epi == EPI_BWD)) {
-      const StageDesc& nd = a.dec.st[s + 1];
-      pipe_out = a.dec.sth[s + 1].n_k16 == 32 && nd.mb_lo == 0 && nd.mb_hi >= 8 && nd.epi != EPI_BWD4 && nd.epi != EPI_BWD0;
-    }
-
-    if (epi == EPI_BWD4 || epi == EPI_BWD0) {          // never entered with a pending block (see pipe_out)
-      reinterpret_cast<f32x4*>(sc)[tid] = reinterpret_cast<const f32x4*>(epi == EPI_BWD4 ? a.dec.w4x : a.dec.w0x)[tid];
-      __syncthreads();
-      const f32x4* wx = reinterpret_cast<const f32x4*>(sc);
-#pragma unroll 2
-      for (int g = 0; g < 8; ++g) {
-        float x[8];
-        load_group<false>(xh, xl, 8 * w + g, lane, x);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const f32x4 wv = wx[64 * w + 8 * g + j];
-          gx0 = fmaf(x[j], wv[0], gx0);
-          gx1 = fmaf(x[j], wv[1], gx1);
-          gx2 = fmaf(x[j], wv[2], gx2);
-        }
-      }
-    }
-
-    const f16x8* wp = reinterpret_cast<const f16x8*>(sh.wp);
-    const f16x8* wp0 = wp + (size_t)(mb0 - sd.mb_lo) * sh.mb_stride + lane;
-    const f16x8* wp1 = wp + (size_t)(mb1 - sd.mb_lo) * sh.mb_stride + lane;
-
-    // ---- loop A: row block mb0; with a pending block 1 of the previous stage, its epilogue rides in the first half ----
-    acc0[0] = zero16h(); acc0[1] = zero16h();
-    if (pend) {
-      const StageDesc& pd = a.dec.st[p_s];
-      const float pus = a.dec.sth[p_s].unscale;
-      if (pd.epi <= EPI_FWD7) {
-        const float* pbias = bl + p_s * HID + mb1 * 32 + 4 * hi;
-        const f32x4 bvp[4] = {*reinterpret_cast<const f32x4*>(pbias), *reinterpret_cast<const f32x4*>(pbias + 8),
-                              *reinterpret_cast<const f32x4*>(pbias + 16), *reinterpret_cast<const f32x4*>(pbias + 24)};
-        uint32_t pbits = 0;
-        gemm_loop_r<true>(acc0, wp0, 0, 16, xh, xl, lane, [&](auto ic) {
-          constexpr int i = decltype(ic)::value;
-          if constexpr (i >= 2 && i < 10) {
-            uint2 hh, ll;
-            fwd_chunk<i - 2>(acc1, bvp, pus, pbits, xm2, hh, ll);
-            store_chunk<i - 2>(xh4, xl4, mb1, hi, qa, hh, ll);
-          }
-        });
-        { const int layer_ = pd.layer;          // shadows: the PENDING stage's layer
-          if (mode == 1) { HM_MASK_SETY(pbits) }
-          if (mode == 0 && sg.mask_out != nullptr)
-            sg.mask_out[(((size_t)b * (sg.n_stride / TQ) + tile) * 8 + layer_) * 512 + tid] = uint2{p_bits0, pbits}; }
-      } else {
-        uint2 pmk;
-#define HM_GET(M) pmk = M
-        switch (pd.layer) { HM_MASK_CASES(HM_GET) }
-#undef HM_GET
-        const uint32_t pbits = pmk.y;
-        gemm_loop_r<true>(acc0, wp0, 0, 16, xh, xl, lane, [&](auto ic) {
-          constexpr int i = decltype(ic)::value;
-          if constexpr (i >= 2 && i < 10) {
-            uint2 hh, ll;
-            bwd_chunk<i - 2>(acc1, pus, pbits, xm2, hh, ll);
-            store_chunk<i - 2>(xh4, xl4, mb1, hi, qa, hh, ll);
-          }
-        });
-      }
-      if (tr) a.trace[s * 8 + 1] = clock64();
-      __syncthreads();                                   // D: rows 256..511 of this stage's input are in place
-      if (tr) a.trace[s * 8 + 2] = clock64();
-      gemm_loop_r<false>(acc0, wp0, 16, n, xh, xl, lane, NoWeave{});
-    } else if (u0) {
-      gemm_loop_r<false>(acc0, wp0, 0, n, xh, xl, lane, NoWeave{});
-    }
-
-    if (tr) a.trace[s * 8 + 3] = clock64();
-    // ---- loop B: row block mb1, with block 0's epilogue arithmetic woven in (results parked in P0) ----
-    acc1[0] = zero16h(); acc1[1] = zero16h();
-    if (epi == EPI_BWD0 && u1) {
-      const float rs = 1.f / us;
-      const int jz = (mb1 - mb_zx) * 32;
-#pragma unroll
-      for (int nb = 0; nb < 2; ++nb) {
-        const int q = nb * 32 + qa;
-        if (q < cnt) {
-          const float* row = Jout + (qbase + q) * (size_t)a.ldJ;
-#pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(row + jz + 8 * g + 4 * hi);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc1[nb][4 * g + j] = v[j] * rs;
-          }
-        }
-      }
-    }
-    Packed P0;
-    uint32_t bits0 = 0, bits1 = 0;
-    uint2 bmk = {0, 0};                                  // backward: mask words of the producing layer
-    if (!is_fwd) {
-#define HM_GET(M) bmk = M
-      switch (layer_) { HM_MASK_CASES(HM_GET) }
-#undef HM_GET
-    }
-    const float* bias = bl + s * HID;
-    // lin3's rows m..m+2 (rows 29..31 of block m >> 5: g = 3, upper half-wave) carry xyz into the skip layer (see
-    // k_decoder_h): the chunks (g = 3, nb) of that block are re-packed with the query coordinates
-    auto splice_xyz = [&](const f32x16 (&ac)[2], int mb, Packed& P) {
-#pragma unroll
-      for (int nb = 0; nb < 2; ++nb) {
-        const f32x4 p = pts4[qbase + nb * 32 + qa];
-        const float v0 = fmaxf(fmaf(ac[nb][12], us, bias[mb * 32 + 24 + 4 * hi]), 0.f);
-        f16x2 unused = xm2;
-        split_pack(f32x2{v0, p[0]}, f32x2{p[1], p[2]}, false, unused, P.hh[6 + nb], P.ll[6 + nb]);
-      }
-    };
-    const bool splice0 = epi == EPI_FWD3 && mb0 == (m >> 5) && hi == 1;
-    const bool splice1 = epi == EPI_FWD3 && mb1 == (m >> 5) && hi == 1;
-    bool done0 = false;
-    if (u1) {
-      if (u0 && n >= 12 && epi != EPI_FWD3) {
-        done0 = true;
-        if (is_fwd) {
-          const float* b0p = bias + mb0 * 32 + 4 * hi;
-          const f32x4 bv0[4] = {*reinterpret_cast<const f32x4*>(b0p), *reinterpret_cast<const f32x4*>(b0p + 8),
-                                *reinterpret_cast<const f32x4*>(b0p + 16), *reinterpret_cast<const f32x4*>(b0p + 24)};
-          gemm_loop_r<true>(acc1, wp1, 0, n, xh, xl, lane, [&](auto ic) {
-            constexpr int i = decltype(ic)::value;
-            if constexpr (i >= 2 && i < 10) fwd_chunk<i - 2>(acc0, bv0, us, bits0, xm2, P0.hh[i - 2], P0.ll[i - 2]);
-          });
-        } else {
-          gemm_loop_r<true>(acc1, wp1, 0, n, xh, xl, lane, [&](auto ic) {
-            constexpr int i = decltype(ic)::value;
-            if constexpr (i >= 2 && i < 10) bwd_chunk<i - 2>(acc0, us, bmk.x, xm2, P0.hh[i - 2], P0.ll[i - 2]);
-          });
-        }
-      } else {
-        gemm_loop_r<false>(acc1, wp1, 0, n, xh, xl, lane, NoWeave{});
-      }
-    }
-    const bool latent1 = (epi == EPI_BWD4 && mb1 >= mb_zx) || epi == EPI_BWD0;     // block 1 goes to the Jacobian row, not to X
-    if (u1 && latent1) {
-      const int jz = (mb1 - mb_zx) * 32;
-#pragma unroll
-      for (int nb = 0; nb < 2; ++nb) {
-        const int q = nb * 32 + qa;
-        if (q < cnt) {
-          float* row = Jout + (qbase + q) * (size_t)a.ldJ;
-#pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            f32x4 v;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = acc1[nb][4 * g + j] * us;
-            *reinterpret_cast<f32x4*>(row + jz + 8 * g + 4 * hi) = v;
-          }
-        }
-      }
-    }
-    if (tr) a.trace[s * 8 + 4] = clock64();
-    __syncthreads();                                     // B: every wave has read this stage's X for the last time
-    if (tr) a.trace[s * 8 + 5] = clock64();
-    // epilogue of a block whose arithmetic did not ride in a K loop: chunk by chunk, straight into X
-    auto finish_block = [&](const f32x16 (&ac)[2], int mb, uint32_t& bits, uint32_t mbits, bool splice) {
-      Packed P;
-      if (is_fwd) {
-        const float* bp = bias + mb * 32 + 4 * hi;
-        const f32x4 bv[4] = {*reinterpret_cast<const f32x4*>(bp), *reinterpret_cast<const f32x4*>(bp + 8),
-                             *reinterpret_cast<const f32x4*>(bp + 16), *reinterpret_cast<const f32x4*>(bp + 24)};
-        fwd_chunk<0>(ac, bv, us, bits, xm2, P.hh[0], P.ll[0]); store_chunk<0>(xh4, xl4, mb, hi, qa, P.hh[0], P.ll[0]);
-        fwd_chunk<1>(ac, bv, us, bits, xm2, P.hh[1], P.ll[1]); store_chunk<1>(xh4, xl4, mb, hi, qa, P.hh[1], P.ll[1]);
-        fwd_chunk<2>(ac, bv, us, bits, xm2, P.hh[2], P.ll[2]); store_chunk<2>(xh4, xl4, mb, hi, qa, P.hh[2], P.ll[2]);
-        fwd_chunk<3>(ac, bv, us, bits, xm2, P.hh[3], P.ll[3]); store_chunk<3>(xh4, xl4, mb, hi, qa, P.hh[3], P.ll[3]);
-        fwd_chunk<4>(ac, bv, us, bits, xm2, P.hh[4], P.ll[4]); store_chunk<4>(xh4, xl4, mb, hi, qa, P.hh[4], P.ll[4]);
-        fwd_chunk<5>(ac, bv, us, bits, xm2, P.hh[5], P.ll[5]); store_chunk<5>(xh4, xl4, mb, hi, qa, P.hh[5], P.ll[5]);
-        fwd_chunk<6>(ac, bv, us, bits, xm2, P.hh[6], P.ll[6]);
-        fwd_chunk<7>(ac, bv, us, bits, xm2, P.hh[7], P.ll[7]);
-        if (splice) splice_xyz(ac, mb, P);
-        store_chunk<6>(xh4, xl4, mb, hi, qa, P.hh[6], P.ll[6]);
-        store_chunk<7>(xh4, xl4, mb, hi, qa, P.hh[7], P.ll[7]);
-      } else {
-        bwd_chunk<0>(ac, us, mbits, xm2, P.hh[0], P.ll[0]); store_chunk<0>(xh4, xl4, mb, hi, qa, P.hh[0], P.ll[0]);
-        bwd_chunk<1>(ac, us, mbits, xm2, P.hh[1], P.ll[1]); store_chunk<1>(xh4, xl4, mb, hi, qa, P.hh[1], P.ll[1]);
-        bwd_chunk<2>(ac, us, mbits, xm2, P.hh[2], P.ll[2]); store_chunk<2>(xh4, xl4, mb, hi, qa, P.hh[2], P.ll[2]);
-        bwd_chunk<3>(ac, us, mbits, xm2, P.hh[3], P.ll[3]); store_chunk<3>(xh4, xl4, mb, hi, qa, P.hh[3], P.ll[3]);
-        bwd_chunk<4>(ac, us, mbits, xm2, P.hh[4], P.ll[4]); store_chunk<4>(xh4, xl4, mb, hi, qa, P.hh[4], P.ll[4]);
-        bwd_chunk<5>(ac, us, mbits, xm2, P.hh[5], P.ll[5]); store_chunk<5>(xh4, xl4, mb, hi, qa, P.hh[5], P.ll[5]);
-        bwd_chunk<6>(ac, us, mbits, xm2, P.hh[6], P.ll[6]); store_chunk<6>(xh4, xl4, mb, hi, qa, P.hh[6], P.ll[6]);
-        bwd_chunk<7>(ac, us, mbits, xm2, P.hh[7], P.ll[7]); store_chunk<7>(xh4, xl4, mb, hi, qa, P.hh[7], P.ll[7]);
-      }
-    };
-    if (u0 && done0) {
-      store_chunk<0>(xh4, xl4, mb0, hi, qa, P0.hh[0], P0.ll[0]); store_chunk<1>(xh4, xl4, mb0, hi, qa, P0.hh[1], P0.ll[1]);
-      store_chunk<2>(xh4, xl4, mb0, hi, qa, P0.hh[2], P0.ll[2]); store_chunk<3>(xh4, xl4, mb0, hi, qa, P0.hh[3], P0.ll[3]);
-      store_chunk<4>(xh4, xl4, mb0, hi, qa, P0.hh[4], P0.ll[4]); store_chunk<5>(xh4, xl4, mb0, hi, qa, P0.hh[5], P0.ll[5]);
-      store_chunk<6>(xh4, xl4, mb0, hi, qa, P0.hh[6], P0.ll[6]); store_chunk<7>(xh4, xl4, mb0, hi, qa, P0.hh[7], P0.ll[7]);
-    } else if (u0) {
-      finish_block(acc0, mb0, bits0, bmk.x, splice0);
-    }
-    if (u1 && !latent1 && !pipe_out) finish_block(acc1, mb1, bits1, bmk.y, splice1);
-    if (is_fwd) {
-      if (mode == 1) { HM_MASK_SETX(bits0) if (!pipe_out) { HM_MASK_SETY(bits1) } }
-      if (mode == 0 && sg.mask_out != nullptr && !pipe_out)
-        sg.mask_out[(((size_t)b * (sg.n_stride / TQ) + tile) * 8 + layer_) * 512 + tid] = uint2{bits0, bits1};
-      p_bits0 = bits0;
-    }
-
-    if (epi == EPI_FWD7) {
-      __syncthreads();
-      float part = 0.f;
-#pragma unroll 2
-      for (int g = 0; g < 8; ++g) {
-        float x[8];
-        load_group(xh, xl, 8 * w + g, lane, x);
-        const f32x4 w0 = *reinterpret_cast<const f32x4*>(bl + 8 * HID + 64 * w + 8 * g);
-        const f32x4 w1 = *reinterpret_cast<const f32x4*>(bl + 8 * HID + 64 * w + 8 * g + 4);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { part = fmaf(x[j], w0[j], part); }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { part = fmaf(x[4 + j], w1[j], part); }
-      }
-      if (__any(!(fmaxf((float)xm2[0], (float)xm2[1]) < 65504.f))) part = __builtin_nanf("");
-      sc[w * 64 + lane] = part;
-      __syncthreads();
-      float a8 = 0.f;
-#pragma unroll
-      for (int i = 0; i < NWAVE; ++i) a8 += sc[i * 64 + lane];
-      a8 += a.dec.b8;
-      const float yv = tanhf(a8);
-      y_keep = yv;
-      if (w == 0) {
-        if (lane < cnt) sg.y[qbase + lane] = yv;
-        sc[2048 + lane] = 1.f - yv * yv;
-      }
-      if (mode == 0) return;
-      __syncthreads();
-      write_g7<false>(xh4, xl4, bl, uint2{bits0, bits1}, mb0, mb1, hi, qa, sc[2048 + qa], sc[2048 + 32 + qa], xm2);
-    }
-    if (tr) a.trace[s * 8 + 6] = clock64();
-    __syncthreads();                                     // C: rows 0..255 (all rows unless `pipe_out`) of the next X visible
-    pend = pipe_out;
-    p_s = s;
-  }
-
-  if (a.trace != nullptr && blockIdx.x == 0 && tid == 0) a.trace[NSTAGE * 8] = clock64();
-  if (mode == 0) return;
-  if (__any(!(fmaxf((float)xm2[0], (float)xm2[1]) < 65504.f))) gx0 = __builtin_nanf("");
-  sc[(w * 4 + 0) * 64 + lane] = gx0;
-  sc[(w * 4 + 1) * 64 + lane] = gx1;
-  sc[(w * 4 + 2) * 64 + lane] = gx2;
-  __syncthreads();
-  if (w == 0 && lane < cnt) {
-    float g0 = 0.f, g1 = 0.f, g2 = 0.f;
-#pragma unroll
-    for (int i = 0; i < NWAVE; ++i) {
-      g0 += sc[(i * 4 + 0) * 64 + lane];
-      g1 += sc[(i * 4 + 1) * 64 + lane];
-      g2 += sc[(i * 4 + 2) * 64 + lane];
-    }
-    const f32x4 p = pts4[qbase + lane];
-    float* row = Jout + (qbase + lane) * (size_t)a.ldJ + L;
-    row[7] = y_keep;
-    row[0] = g0; row[1] = g1; row[2] = g2;
-    if (sg.pose_dim != 0) {
-      row[3] = g2 * p[1] - g1 * p[2];
-      row[4] = g0 * p[2] - g2 * p[0];
-      row[5] = g1 * p[0] - g0 * p[1];
-      if (sg.pose_dim == 7) row[6] = g0 * p[0] + g1 * p[1] + g2 * p[2];
-    }
-  }
-}
-#undef HM_MASK_SETX
-#undef HM_MASK_SETY
+#ifdef HM_EXPERIMENTAL      // scripts/build_variant.sh exp -DHM_EXPERIMENTAL: the round-4 schedule experiments (measured slower)
+#include "experimental/hm_decoder_g.inc"
+#endif
 
 }  // namespace
 
 static long long* g_trace = nullptr;
 static int g_trace_tid = 0;
 extern "C" void hm_debug_set_trace_thread(int tid) { g_trace_tid = tid; }
-// f16x3 kernel variant: 0 (default) = k_decoder_h (both row blocks in one K loop, epilogues between two barriers),
-// 1 = k_decoder_hs (row blocks staggered, epilogues woven into the K loops).  Same bits.  The staggered kernel removes the
-// idle-pipe epilogue interval as designed, but MEASURED 2.5-3.5 % slower on the same box (profiles/r03_k1hs_trace.txt): the
-// stage time is set by the YOUNGER wave of each SIMD pair, whose K loops take 35 k clocks against 27 k for the older
-// (issue arbitration is priority-then-age); the older waves merely move their idle time from the epilogue to the barriers,
-// and the split loops read the activations from LDS twice.  Kept for the evidence and as a base for further experiments.
-static int g_k1h_stagger = 0;
-extern "C" void hm_debug_k1h_stagger(int on) { g_k1h_stagger = on ? 1 : 0; }
+#ifdef HM_EXPERIMENTAL
+// Experimental builds only: f16x3 kernel variant 0 = k_decoder_h (product), 1 = k_decoder_g<., true> (ping-pong wave groups),
+// 2 = k_decoder_g<., false> (lockstep, raw barriers, primed four-set weight ring); tune = DecodeArgsH::tune.  Same bits.
+static int g_k1h_tune = 0;
+extern "C" void hm_debug_k1h_tune(int t) { g_k1h_tune = t; }
+static int g_k1h_variant = 0;
+extern "C" void hm_debug_k1h_variant(int v) { g_k1h_variant = (v >= 0 && v <= 2) ? v : 0; }
+#endif
 extern "C" void hm_debug_set_trace(long long* d_buf) { g_trace = d_buf; }
 
 namespace hm {
@@ -1271,8 +769,14 @@ int launch_h(const hm_decoder_s* dec, DecodeArgsH& a, int grid, hipStream_t stre
   a.dec = dec->dev;
   a.trace = g_trace;
   a.trace_tid = g_trace_tid;
+#ifdef HM_EXPERIMENTAL
+  a.tune = g_k1h_tune;
+#endif
   if (dec->precision == 2) hipLaunchKernelGGL((k_decoder_h<TAG, true>), dim3(grid), dim3(512), 0, stream, a);
-  else if (g_k1h_stagger) hipLaunchKernelGGL((k_decoder_hs<TAG>), dim3(grid), dim3(512), 0, stream, a);
+#ifdef HM_EXPERIMENTAL
+  else if (g_k1h_variant == 1) hipLaunchKernelGGL((k_decoder_g<TAG, true>), dim3(grid), dim3(512), 0, stream, a);
+  else if (g_k1h_variant == 2) hipLaunchKernelGGL((k_decoder_g<TAG, false>), dim3(grid), dim3(512), 0, stream, a);
+#endif
   else hipLaunchKernelGGL((k_decoder_h<TAG, false>), dim3(grid), dim3(512), 0, stream, a);
   HM_CHECK_HIP(hipGetLastError());
   return 0;

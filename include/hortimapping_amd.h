@@ -190,11 +190,9 @@ int hm_render_residuals(hm_workspace_t ws, const hm_opt_cfg* cfg, const hm_batch
 
 /* ---- performance-analysis aids (not part of the drop-in surface): when a device buffer is registered, block 0 of
  * the f16x3 decoder kernel / of the solve kernel writes shader-clock stamps per stage into it (scripts/gpu_trace_*.py). */
-void hm_debug_set_trace(long long* d_buf);      /* [NSTAGE * 4 + 1] or NULL */
+void hm_debug_set_trace(long long* d_buf);      /* [NSTAGE * 8 + 1] or NULL (the product kernel writes [NSTAGE * 4 + 1] of it) */
 void hm_debug_set_k5_trace(long long* d_buf);   /* [32] or NULL */
 void hm_debug_force_direct_solve(int on);        /* tests: 1 = every solve takes the blocked-Cholesky fallback of K5 */
-void hm_debug_k1h_stagger(int on);               /* A/B + tests: 0 (default) = the two-barrier f16x3 decoder kernel (k_decoder_h),
-                                                  * 1 = the staggered kernel (k_decoder_hs, measured slower); same bits */
 void hm_debug_set_trace_thread(int tid);         /* which thread of workgroup 0 writes the hm_debug_set_trace stamps */
 void hm_debug_split_render(int on);              /* A/B + tests: 1 = the f16x3 render chain as separate launches with a
                                                   * forward+backward Jacobian pass (round 2) instead of the fused grid +

@@ -74,62 +74,3 @@ def test_optimisation_fused_equals_split(precision, L):
         assert a.iter_count == b.iter_count and a.status == b.status
         assert torch.equal(a.latent, b.latent) and torch.equal(a.T_ow, b.T_ow)
     assert all(torch.isfinite(r.latent).all() for r in out[0])
-
-
-def _stagger(on):
-    from hortimapping_amd import _lib
-    _lib.lib().hm_debug_k1h_stagger(int(on))
-
-
-@pytest.fixture(autouse=True)
-def _restore_stagger():
-    yield
-    _stagger(0)
-
-
-@pytest.mark.parametrize("L", [32, 64, 128, 256])
-def test_staggered_kernel_equals_the_two_barrier_kernel(L):
-    """k_decoder_hs (row blocks one after the other, epilogue arithmetic woven into the K loops, block 1's epilogue carried
-    into the next stage) computes the same products in the same order as k_decoder_h: sdf values, Jacobian rows and the
-    NaN-poison behaviour identical BIT FOR BIT, for every latent size (the stage shapes differ: L = 32 has 480-wide skip
-    stages, the xyz splice sits in a different wave's block) and ragged tile tails."""
-    from hortimapping_amd import ops, synthetic as S
-    from hortimapping_amd.decoder import DecoderWeights
-    dec = DecoderWeights.from_params(S.make_synthetic_decoder(L, seed=7, r0=0.04, aniso=(1.0, 0.75, 1.3), bias_sigma=0.02))
-    dec.set_precision("f16x3")
-    g = torch.Generator().manual_seed(L)
-    B, n = 3, 200
-    lat = (0.07 * torch.randn(B, L, generator=g)).cuda()
-    pts4 = torch.zeros(B, 256, 4)
-    pts4[..., :3] = 0.05 * torch.randn(B, 256, 3, generator=g)
-    pts4 = pts4.cuda()
-    nq = torch.tensor([n, 64, 1], dtype=torch.int32).cuda()
-    out = {}
-    for st in (0, 1):
-        _stagger(st)
-        y0, _ = ops.decode_batch(dec, lat, pts4, nq, mode=0)
-        y1, J1 = ops.decode_batch(dec, lat, pts4, nq, mode=1, pose_dim=7)
-        out[st] = (y0.clone(), y1.clone(), J1.clone())
-    for b, k in enumerate((n, 64, 1)):
-        for a_, b_ in zip(out[0], out[1]):
-            assert torch.equal(a_[b, :k], b_[b, :k]), (L, b)
-    assert torch.isfinite(out[1][2][0, :n]).all() and float(out[1][2][0, :n, :L].abs().max()) > 0
-
-
-@pytest.mark.parametrize("L", [32, 256])
-def test_staggered_kernel_whole_optimisation_bits(L):
-    """The joint optimisation (fused main launch, backward-only render pass) with either f16x3 kernel variant: same bits."""
-    from hortimapping_amd import optimizer as HO, synthetic as S, workloads as W
-    from hortimapping_amd.decoder import DecoderWeights
-    p = S.make_synthetic_decoder(L, seed=2 if L == 256 else 1, r0=0.04, aniso=(1.0, 0.75, 1.3))
-    dec = DecoderWeights.from_params(p).set_precision("f16x3")
-    Ws, bs = S.fold_weight_norm(p)
-    fac = W.gpu_sdf_factory(dec)
-    dicts = [S.make_instance(Ws, bs, L, i, n_pts=300 + 37 * i, n_frames=1 + i % 2, n_fg=40, n_bg=24, sdf_fn_factory=fac) for i in range(4)]
-    opt = W.c2_opt_cfg(max_iter=6, n_sample_on_ray=16, n_frame=2)
-    out = {}
-    for st in (0, 1):
-        _stagger(st)
-        out[st] = HO.optimize_batch(dec, opt, [W.to_instance(d) for d in dicts])
-    for a, b in zip(out[0], out[1]):
-        assert a.iter_count == b.iter_count == 6 and torch.equal(a.latent, b.latent) and torch.equal(a.T_ow, b.T_ow)
