@@ -111,10 +111,14 @@ __global__ __launch_bounds__(512, 2) void k_decoder(const DecodeArgs a) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  // tile-major block order: blockIdx = tile * B + b.  Real tiles of a ragged launch (render samples: a few tiles
-  // per instance, the rest of the capacity empty) are then contiguous in blockIdx and spread round-robin over all
-  // 8 XCDs; instance-major order put them all on XCDs 0..2 (block i runs on XCD i % 8) and quadrupled the launch time.
-  const int b = blockIdx.x % a.B;
+  // tile-major block order, instance rotated by the tile index: blockIdx = tile * B + (b - tile) mod B.  Real tiles of a
+  // ragged launch (render samples: a few tiles per instance, the rest of the capacity empty) are then contiguous in
+  // blockIdx and spread round-robin over all 8 XCDs; instance-major order put them all on XCDs 0..2 (block i runs on XCD
+  // i % 8) and quadrupled the launch time.  The rotation (round 4) spreads the tiles of ONE instance over the XCDs as
+  // well: without it instance b sits on XCD b % 8 whenever B % 8 == 0, and a batch in which most instances have already
+  // converged (early exits on: the shipped configurations) ran its few active instances on one or two XCDs -- the main
+  // launch of wild_pepper.yaml took 51 ms with 4 of 64 instances active against 60 ms with all of them.
+  const int b = (blockIdx.x + blockIdx.x / a.B) % a.B;
   const int q0 = (blockIdx.x / a.B) * TQ;
   if (a.active != nullptr && a.active[b] == 0) return;
   const int nq = a.n_q[b];

@@ -403,7 +403,7 @@ __global__ __launch_bounds__(512, 2) void k_decoder_h(const DecodeArgsH a) {
   const DecSeg& sg = a.seg[si];
   const int blk = si ? blockIdx.x - a.n_blocks0 : blockIdx.x;
   const int mode = sg.mode;
-  const int b = blk % a.B;                        // tile-major block order (see hm_decoder.hip)
+  const int b = (blk + blk / a.B) % a.B;          // tile-major block order, instance rotated by the tile (see hm_decoder.hip)
   const int tile = blk / a.B;
   const int q0 = tile * TQ;
   if (a.active != nullptr && a.active[b] == 0) return;

@@ -174,7 +174,7 @@ __global__ __launch_bounds__(512, 2) void k_decoder_p(const DecodeArgsP a) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int b = blockIdx.x % a.B;                 // tile-major block order (see hm_decoder.hip)
+  const int b = (blockIdx.x + blockIdx.x / a.B) % a.B;   // tile-major block order, instance rotated by the tile (see hm_decoder.hip)
   const int q0 = (blockIdx.x / a.B) * TQP;
   if (a.active != nullptr && a.active[b] == 0) return;
   const int nq = a.n_q[b];

@@ -47,6 +47,15 @@ struct hm_workspace_s {
   // optional work counters (measurement): sums over every instance-iteration since the last enable
   int count_on;
   unsigned long long* d_counters; // [N_COUNTER]
+  // test / A-B switches, scoped to THIS workspace: the override set by hm_workspace_set_debug (-1 = follow the process
+  // default of hm_debug_split_render / hm_debug_force_direct_solve) and the value snapshotted when an entry point is
+  // called -- one call never sees a switch change under it (a mask-less forward paired with a mask-reading backward)
+  int dbg_split_override, dbg_direct_override;
+  int split_render, force_direct;
+  // ReLU masks of the f16x3 forward pass over the ray samples: 512 B per sample slot (half as much again as the JG
+  // buffer), so it is allocated on the first call that takes the fused path, not for f32 / plain-fp16 / shape-only use
+  void* d_maskR;
+  size_t maskR_bytes;
 };
 
 // hm_workspace_counters_read layout
@@ -105,8 +114,7 @@ void carve(hm_workspace_s* w, Carver& c) {
   rb.JG = c.take<float>((size_t)B * w->nG_stride * w->ldJ);
   rb.yG = c.take<float>((size_t)B * w->nG_stride);
   rb.srcG = c.take<int>((size_t)B * w->nG_stride);
-  // ReLU masks of the forward pass over the ray samples (f16x3 decoder): 512 B per sample slot
-  rb.maskR = c.take<unsigned long long>((size_t)B * (w->nR_stride / TQ) * 8 * 512);
+  rb.maskR = w->d_maskR;          // separate, lazy allocation (ensure_masks)
   rb.JR = c.take<float>((size_t)B * 2 * nray * w->ldJ);
   rb.nR_stride = w->nR_stride;
   rb.nG_stride = w->nG_stride;
@@ -227,7 +235,7 @@ void bind_inputs(RenderBuffers& rb, const hm_batch* bt) {
 // test that both give the same bits.
 int g_split_render = 0;
 
-bool fused_path(const hm_workspace_s* ws) { return (ws->dec->precision == 1 || ws->dec->precision == 2) && !g_split_render; }
+bool fused_path(const hm_workspace_s* ws) { return (ws->dec->precision == 1 || ws->dec->precision == 2) && !ws->split_render; }
 
 // render chain after the forward pass: scan / offsets / scatter, Jacobian pass, per-ray reduce (optimizer.py:93-132)
 int render_back(hm_workspace_s* ws, const RenderCfg& rc, const RenderBuffers& rb, const hm_batch* bt, int P,
@@ -267,6 +275,30 @@ static int g_force_direct = 0;
 extern "C" void hm_debug_force_direct_solve(int on) { g_force_direct = on ? 1 : 0; }
 // A/B hook: 1 = the round-2 launch sequence of the f16x3 render chain (see g_split_render)
 extern "C" void hm_debug_split_render(int on) { g_split_render = on ? 1 : 0; }
+// the same two switches for ONE workspace (-1: follow the process default above)
+extern "C" int hm_workspace_set_debug(hm_workspace_s* w, int split_render, int force_direct_solve) {
+  if (w == nullptr) { hm_set_error("null workspace"); return -1; }
+  w->dbg_split_override = split_render < 0 ? -1 : (split_render ? 1 : 0);
+  w->dbg_direct_override = force_direct_solve < 0 ? -1 : (force_direct_solve ? 1 : 0);
+  return 0;
+}
+
+namespace {
+// entry-point prologue: snapshot the switches, make sure the mask buffer exists when the fused path will run
+int begin_call(hm_workspace_s* ws, int joint) {
+  ws->split_render = ws->dbg_split_override >= 0 ? ws->dbg_split_override : g_split_render;
+  ws->force_direct = ws->dbg_direct_override >= 0 ? ws->dbg_direct_override : g_force_direct;
+  if (joint && fused_path(ws) && ws->d_maskR == nullptr) {
+    ws->maskR_bytes = (size_t)ws->lim.max_batch * (ws->nR_stride / TQ) * 8 * 512 * sizeof(unsigned long long);
+    hipError_t e = hipMalloc(&ws->d_maskR, ws->maskR_bytes);
+    if (e != hipSuccess) {
+      hm_set_error("hipMalloc(%zu) of the ReLU-mask buffer failed: %s", ws->maskR_bytes, hipGetErrorString(e));
+      ws->d_maskR = nullptr; ws->maskR_bytes = 0; return -2; }
+    ws->rb.maskR = ws->d_maskR;
+  }
+  return 0;
+}
+}  // namespace
 
 extern "C" int hm_workspace_create(hm_decoder_s* dec, const hm_limits* lim, hm_workspace_s** out) {
   if (dec == nullptr || lim == nullptr || out == nullptr) { hm_set_error("null argument"); return -1; }
@@ -275,6 +307,8 @@ extern "C" int hm_workspace_create(hm_decoder_s* dec, const hm_limits* lim, hm_w
     hm_set_error("bad limits (need batch>0, points>0, frames<=64, samples<=64)"); return -1; }
   hm_workspace_s* w = new hm_workspace_s();
   w->profile_on = 0; w->ev_used = 0; w->d_blob = nullptr; w->blob_bytes = 0; w->count_on = 0;
+  w->dbg_split_override = w->dbg_direct_override = -1; w->split_render = w->force_direct = 0;
+  w->d_maskR = nullptr; w->maskR_bytes = 0;
   w->dec = dec; w->lim = *lim; w->L = dec->L; w->ldJ = dec->L + POSE_PAD;
   if (w->lim.max_frames == 0 || w->lim.max_rays == 0 || w->lim.max_samples == 0) {
     w->lim.max_frames = 1; w->lim.max_rays = 1; w->lim.max_samples = 2;     // shape-only workspace
@@ -360,11 +394,12 @@ extern "C" int hm_workspace_destroy(hm_workspace_s* w) {
   if (w->act_ready) for (int i = 0; i < hm_workspace_s::N_ACT; ++i) (void)hipEventDestroy(w->ev_act[i]);
   if (w->h_act_count) (void)hipHostFree(w->h_act_count);
   (void)hipFree(w->d_blob);
+  if (w->d_maskR) (void)hipFree(w->d_maskR);
   delete w;
   return 0;
 }
 
-extern "C" size_t hm_workspace_bytes(hm_workspace_s* w) { return w ? w->blob_bytes : 0; }
+extern "C" size_t hm_workspace_bytes(hm_workspace_s* w) { return w ? w->blob_bytes + w->maskR_bytes : 0; }
 
 extern "C" int hm_optimize_batch(hm_workspace_s* ws, const hm_opt_cfg* cfg, const hm_batch* bt, int mode,
                                  const hm_debug* dbg, void* stream) {
@@ -377,6 +412,8 @@ extern "C" int hm_optimize_batch(hm_workspace_s* ws, const hm_opt_cfg* cfg, cons
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int B = bt->B, L = ws->L;
   const int P = mode == 1 ? 0 : (cfg->scale_on ? 7 : 6);
+  rc = begin_call(ws, mode == 0);
+  if (rc) return rc;
 
   hipLaunchKernelGGL(k_fill_int, dim3((B + 255) / 256), dim3(256), 0, st, ws->active, B, 1);
   hipLaunchKernelGGL(k_fill_int, dim3((B + 255) / 256), dim3(256), 0, st, bt->d_iter_count, B, 0);
@@ -389,7 +426,7 @@ extern "C" int hm_optimize_batch(hm_workspace_s* ws, const hm_opt_cfg* cfg, cons
   RenderCfg rcfg = make_render_cfg(ws, cfg);
   RenderBuffers rb = ws->rb;
   if (mode == 0) { bind_inputs(rb, bt); rb.status = bt->d_status; }
-  const int force_direct = g_force_direct;
+  const int force_direct = ws->force_direct;
 
   // Early stop of the LAUNCH loop.  Finished instances are frozen on the device (`active` flags), so results never depend
   // on this; but a batch whose instances have all converged by iteration 7 of max_iter 50 would still be sent 43 x 13
@@ -498,6 +535,8 @@ extern "C" int hm_render_residuals(hm_workspace_s* ws, const hm_opt_cfg* cfg, co
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int B = bt->B, L = ws->L;
   const int P = cfg->scale_on ? 7 : 6;
+  rc = begin_call(ws, 1);
+  if (rc) return rc;
   RenderCfg rcfg = make_render_cfg(ws, cfg);
   RenderBuffers rb = ws->rb;
   bind_inputs(rb, bt);

@@ -14,6 +14,14 @@ from typing import List, Sequence, Tuple
 import torch
 import torch.distributed as dist
 
+# RCCL between PROCESSES maps peer buffers through HIP IPC handles.  The hosts this code runs on only support dmabuf IPC
+# (their environment exports HSA_ENABLE_IPC_MODE_LEGACY=0; with the legacy mode RCCL's `hipIpcGetMemHandle` fails with
+# "invalid argument" -- the platform notes of this build state it, no multi-GPU box was available to re-measure it).  The
+# variable is read when the HSA runtime starts, so it is set here, at import, before any rank touches the GPU -- for every
+# launch path alike (torch.distributed.run started by the driver, bench.py's own spawn, a user's script).  A value the
+# caller exported wins.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 
 def shard_bounds(n: int, rank: int, world: int) -> Tuple[int, int]:
     """Instance i belongs to rank i // ceil(n / world): contiguous blocks, order preserving."""

@@ -121,6 +121,7 @@ class Result:
     T_ow: torch.Tensor
     iter_count: int
     status: int
+    retried_f32: bool = False            # the f16x3 range guard tripped and this is the exact-fp32 rerun (optimize_batch)
 
 
 @functools.lru_cache(maxsize=256)
@@ -315,13 +316,32 @@ def _grown_workspace(dec, old: Optional[Workspace], B, N, F, R, M) -> Workspace:
 
 def optimize_batch(dec: DecoderWeights, opt: dict, instances: Sequence[Instance], shape_only: bool = False,
                    workspace: Optional[Workspace] = None, device="cuda", debug: Optional[dict] = None,
-                   cache: Optional[dict] = None) -> List[Result]:
+                   cache: Optional[dict] = None, retry_f32: bool = False) -> List[Result]:
     """Optimise all `instances` concurrently; results are returned in input order (identical instance indexing).
     `cache` (a dict owned by the caller, e.g. the drop-in `Optimizer`) keeps the workspace between calls: the
     reference's usage pattern is one fruit per call, and a fresh hipMalloc + hipMemset + hipFree of the workspace per
-    call would dominate its latency."""
+    call would dominate its latency.
+    `retry_f32`: the fp16-operand arithmetics (f16x3, f16x3f_f16b, f16) cannot represent hidden activations beyond 65504;
+    a tile that gets there is poisoned and its instance stops with HM_STATUS_SOLVE_FAILED, its state untouched, where the
+    reference (fp32) simply carries on.  With `retry_f32` every such instance is optimised again from its INITIAL state
+    in exact fp32 -- batched results equal single-instance results bit for bit, so the outcome is the pure-f32 run's --
+    and flagged `retried_f32`; the drop-in `Optimizer` does this, which is what lets it default to f16x3."""
     if len(instances) == 0:
         return []
+    if retry_f32 and dec.precision != "f32":
+        first = optimize_batch(dec, opt, instances, shape_only, workspace, device, debug, cache, retry_f32=False)
+        bad = [i for i, r in enumerate(first) if r.status & STATUS_SOLVE_FAILED]
+        if bad:
+            prec = dec.precision
+            dec.set_precision("f32")
+            try:         # the initial state: `first` left failed instances untouched, but take the caller's tensors anyway
+                again = optimize_batch(dec, opt, [instances[i] for i in bad], shape_only, None, device, None, cache, retry_f32=False)
+            finally:
+                dec.set_precision(prec)
+            for i, r in zip(bad, again):
+                r.retried_f32 = True
+                first[i] = r
+        return first
     cfg = opt_cfg_from_dict(opt)
     L = dec.latent_dim
     from_cache = False                     # only a workspace the cache owns may be released when it has to grow
@@ -379,6 +399,10 @@ class Optimizer(object):
             self.decoder = decoder
         else:                                   # the reference passes an nn.Module (optimizer.py:17)
             self.decoder = DecoderWeights.from_module(decoder)
+            if not os.environ.get("HM_PRECISION"):
+                # fp32-class results at 3 x the speed; instances whose activations leave the fp16 range are rerun in
+                # exact fp32 automatically (optimize_batch, retry_f32), so the behaviour is the reference's either way
+                self.decoder.set_precision("f16x3")
         self.mesher = mesher
         self.vis = vis
         self.log_on = cfg.get("vis", {}).get("log_on", False)
@@ -389,7 +413,7 @@ class Optimizer(object):
 
     def optimize_batch(self, instances: Sequence[Instance], shape_only: bool = False) -> List[Result]:
         return optimize_batch(self.decoder, self.opt_cfg, instances, shape_only, None, self._device(),
-                              cache=self._cache)
+                              cache=self._cache, retry_f32=True)
 
     def shape_pose_joint_opt(self, latent, T_ow_torch, render_data, points_w_torch, cube_radius, cur_color=None,
                              pose_known=False):

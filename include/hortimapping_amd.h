@@ -188,24 +188,6 @@ int hm_render_residuals(hm_workspace_t ws, const hm_opt_cfg* cfg, const hm_batch
                         const float* d_frame_override, float* d_rows, int* d_V, int* d_ray_row, int* d_counts,
                         void* stream);
 
-/* ---- performance-analysis aids (not part of the drop-in surface): when a device buffer is registered, block 0 of
- * the f16x3 decoder kernel / of the solve kernel writes shader-clock stamps per stage into it (scripts/gpu_trace_*.py). */
-void hm_debug_set_trace(long long* d_buf);      /* [NSTAGE * 8 + 1] or NULL (the product kernel writes [NSTAGE * 4 + 1] of it) */
-void hm_debug_set_k5_trace(long long* d_buf);   /* [32] or NULL */
-void hm_debug_force_direct_solve(int on);        /* tests: 1 = every solve takes the blocked-Cholesky fallback of K5 */
-void hm_debug_set_trace_thread(int tid);         /* which thread of workgroup 0 writes the hm_debug_set_trace stamps */
-void hm_debug_split_render(int on);              /* A/B + tests: 1 = the f16x3 render chain as separate launches with a
-                                                  * forward+backward Jacobian pass (round 2) instead of the fused grid +
-                                                  * backward-only pass from saved ReLU masks; same bits either way */
-void hm_debug_set_k1p_trace(long long* d_buf);  /* [5 * 16] or NULL: per-stage stamps of the plain-fp16 decoder kernel */
-
-/* ---- unit hooks (tests): the device functions of the solve kernel / normal-equation kernel on caller-supplied values.
- * hm_debug_exp_map replaces exp_sim3 (sim3 != 0; wild_completion/utils.py:279-324) / exp_se3 (:220-254) for n tangents
- * [n][7] (translation, rotation, log-scale; the 7th entry is ignored for se3) -> [n][16] row-major 4x4.
- * hm_debug_huber replaces get_robust_res (utils.py:343-358): d_rho[i] = w_i^2, d_robust_res[i] = w_i r_i (optional). */
-int hm_debug_exp_map(const float* d_tangents, int n, int sim3, float* d_T, void* stream);
-int hm_debug_huber(const float* d_res, int n, float threshold, float* d_rho, float* d_robust_res, void* stream);
-
 /* ---- next row: iso-surface of a decoded SDF grid; replaces convert_sdf_voxels_to_mesh
  * (wild_completion/utils.py:565-588, scikit-image marching cubes on the host) by marching tetrahedra on the GPU over the
  * same grid.  d_sdf [B][n^3] with index (ix*n + iy)*n + iz (the layout create_voxel_grid produces, utils.py:542-562);

@@ -34,6 +34,48 @@ def ks_upper(u, K):
     return dplus, float(np.exp(-2.0 * n * dplus * dplus))
 
 
+def ks_min_p(n, K):
+    """Smallest p the KS gate can return with n ranked instances and K perturbed runs (every candidate beyond all of its
+    perturbed runs: D+ = K / (K + 1)).  A gate whose min p is not below alpha can never fail: it has no power."""
+    if n == 0:
+        return 1.0
+    d = K / (K + 1.0)
+    return float(np.exp(-2.0 * n * d * d))
+
+
+def exchange_test(dev, pert_dev, n_mc=20000, seed=0):
+    """Exchangeability test with magnitudes, over ALL instances (no floor, no ranking of a few survivors):
+        T = mean_i log( dev_i / max_k pert_dev[k, i] )
+    against its null distribution "the candidate is one more perturbed run": for every instance draw one of the K
+    perturbed runs as a stand-in candidate and compare it with the max of the OTHER K - 1 (a max over one run fewer is a
+    little smaller, which makes the stand-ins look slightly worse, i.e. the test slightly conservative).  One-sided
+    Monte-Carlo p = P(T_null >= T).  Instances where every deviation is exactly zero (a metric the mode pins, e.g. the
+    rotation in pose_known mode) carry no information and are dropped.  Where the rank / KS gate keeps 5-10 instances in
+    pose_known mode and cannot tell 1e-3 Jacobians from fp32-class ones (round-3 VERDICT), this statistic uses all 64
+    and separates them by many sigma (mean log-ratio -1.4 for f32 / f16x3 against -0.3 for the mixed mode)."""
+    dev = np.asarray(dev, dtype=np.float64)
+    D = np.asarray(pert_dev, dtype=np.float64)
+    K, n = D.shape
+    live = (D.max(axis=0) > 0) | (dev > 0)
+    dev, D = dev[live], D[:, live]
+    n = dev.shape[0]
+    if n == 0 or K < 2:
+        return {"n": n, "T": 0.0, "null_mean": 0.0, "null_sd": 0.0, "p": 1.0, "z": 0.0}
+    tiny = 1e-300
+    T = float(np.mean(np.log(np.maximum(dev, tiny) / np.maximum(D.max(axis=0), tiny))))
+    # leave-one-out ratios of the perturbed runs themselves: r[k, i] = D[k, i] / max_{j != k} D[j, i]
+    order = np.sort(D, axis=0)
+    top, second = order[-1], order[-2]
+    others_max = np.where(D == top[None], second[None], top[None])      # (ties: the max itself)
+    r = np.log(np.maximum(D, tiny) / np.maximum(others_max, tiny))
+    rs = np.random.RandomState(seed)
+    pick = rs.randint(0, K, size=(n_mc, n))
+    Tn = r[pick, np.arange(n)[None]].mean(axis=1)
+    p = float((np.sum(Tn >= T) + 1.0) / (n_mc + 1.0))
+    sd = float(Tn.std())
+    return {"n": n, "T": T, "null_mean": float(Tn.mean()), "null_sd": sd, "p": p, "z": float((T - Tn.mean()) / max(sd, 1e-30))}
+
+
 def gate(dev, pert_dev, floor, alpha=1e-3):
     """Full-size gate for ONE metric.  dev: (n,) |m_candidate - m_nominal|; pert_dev: (K, n) |m_pert_k - m_nominal|;
     floor: (n,) the outright tolerance (BASELINE.json: 1e-4 relative).  An instance inside the floor passes outright;
@@ -45,4 +87,5 @@ def gate(dev, pert_dev, floor, alpha=1e-3):
     u = rank_fraction(dev[idx], pert_dev[:, idx]) if len(idx) else np.zeros(0)
     dplus, p = ks_upper(u, K)
     return {"n": len(dev), "outright": int(outright.sum()), "ranked": len(idx), "mean_rank": float(u.mean()) if len(idx) else 0.5,
-            "top_rank": int((u >= 1.0).sum()), "ks": dplus, "p": p, "ok": bool(p >= alpha), "u": u, "idx": idx}
+            "top_rank": int((u >= 1.0).sum()), "ks": dplus, "p": p, "ok": bool(p >= alpha), "u": u, "idx": idx,
+            "min_p": ks_min_p(len(idx), K), "has_power": bool(ks_min_p(len(idx), K) < alpha)}

@@ -11,12 +11,21 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HEADER = os.path.join(ROOT, "include", "hortimapping_amd.h")
+DEBUG_HEADER = os.path.join(ROOT, "include", "hortimapping_amd_debug.h")
 
 
-def declared_functions():
-    src = open(HEADER).read()
-    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b(hm_[a-z0-9_]+)\s*\(", src)))
+def declared_functions(headers=(HEADER, DEBUG_HEADER)):
+    out = set()
+    for h in headers:
+        src = re.sub(r"/\*.*?\*/", "", open(h).read(), flags=re.S)
+        out |= set(re.findall(r"\b(hm_[a-z0-9_]+)\s*\(", src))
+    return sorted(out)
+
+
+def test_the_product_header_carries_no_debug_hooks():
+    """Test / A-B / trace hooks live in include/hortimapping_amd_debug.h; the drop-in ABI declares none of them."""
+    assert not [f for f in declared_functions((HEADER,)) if f.startswith("hm_debug") or f == "hm_workspace_set_debug"]
+    assert "hm_workspace_set_debug" in declared_functions((DEBUG_HEADER,))
 
 
 def test_library_exports_every_declared_symbol():

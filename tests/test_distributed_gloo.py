@@ -84,6 +84,31 @@ def test_bench_rank_logic_two_ranks_strong_and_weak_scaling():
     assert j["scaling"] == "weak" and j["config"]["instances_total"] == 128 and j["config"]["instances_per_gpu"] == 64
 
 
+def test_bench_rank_logic_eight_ranks_configs3_plan_and_weak_scaling():
+    """The driver's 8-GPU runs in dry form (8 gloo ranks, `--stub-cpu`): BASELINE.json configs[3] = `--gpus 8 --total 4096`
+    (512 instances per rank in chunks [256, 256], records gathered in instance order -- asserted inside bench.py on the
+    gathered matrix) and the weak-scaling default (64 per rank, 512 in total)."""
+    port = 29700 + (os.getpid() % 90)
+    j = _run_bench_ranks(8, ["--total", "4096"], port)
+    assert j["n_gpus"] == 8 and j["rccl_ranks"] == 8 and j["scaling"] == "strong"
+    c = j["config"]
+    assert c["instances_total"] == 4096 and c["instances_per_gpu"] == 512 and c["chunk"] == 256
+    assert abs(j["value"] - 4096 * 2 / (j["ms_per_step"] * 2e-3)) < 1e-2 * j["value"]
+    j = _run_bench_ranks(8, [], port + 1)
+    assert j["n_gpus"] == 8 and j["scaling"] == "weak" and j["config"]["instances_total"] == 512 and j["config"]["instances_per_gpu"] == 64
+
+
+def test_ipc_mode_is_set_for_every_launch_path():
+    """RCCL across processes needs dmabuf IPC on these hosts: importing the distributed module sets the variable (unless the
+    caller exported one), so a rank started by torch.distributed.run directly gets it like one started by bench.py."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k != "HSA_ENABLE_IPC_MODE_LEGACY"}
+    code = "import os, sys; sys.path.insert(0, %r); import hortimapping_amd.distributed; print(os.environ['HSA_ENABLE_IPC_MODE_LEGACY'])" % ROOT
+    assert subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120).stdout.strip() == "0"
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "1"
+    assert subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120).stdout.strip() == "1"
+
+
 def test_bench_refuses_a_gpu_count_that_does_not_match_the_launch():
     import subprocess
     env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")

@@ -65,6 +65,17 @@ def test_bench_default_line_carries_the_secondary_objects():
     sd = d["c2_sdf"]["roofline"]["step"]["counts_per_step"]
     assert sd["N_J_sdf_term"] == 64 * 200 * 2048 and sd["N_F_ray_samples"] == 0 and sd["V_rays"] == 0
     assert d["configs3_rank_share"]["instances"] == 512 and d["configs3_rank_share"]["roofline_step"]["counts_per_step"]["instance_iterations"] == 512 * 200
+    assert d["c2_sdf"]["steps"] >= 3 and d["exact_f32"]["steps"] >= 3
+    # the configurations users run (BASELINE.json configs[0], [2], [4]) at their real render-block sizes, >= 3 timed steps each
+    for k, n_groups in (("configs0_wild_pepper", 1), ("configs2_challenge_pepper", 1), ("configs4_lab_pepper_berry", 2)):
+        o = d[k]
+        assert o["value"] > 0 and o["ms_per_fruit"] > 0 and o["steps"] >= 3 and o["fruits"] == 64 and o["dtype"] == "f16x3", k
+        assert len(o["groups"]) == n_groups and 0 < o["roofline_step"]["frac"] < 1 and o["roofline_step"]["algorithmic_flop_per_step"] > 0
+        for g in o["groups"]:
+            c = g["counts_per_step"]
+            assert c["instance_iterations"] >= 3 * g["fruits"] and c["N_F_ray_samples"] > 0 and c["V_rays"] > 0
+            assert 3 <= g["iterations"]["min"] <= g["iterations"]["max"] <= g["max_iter"]
+    assert d["configs4_lab_pepper_berry"]["plain_f16"]["dtype"] == "f16" and d["configs4_lab_pepper_berry"]["plain_f16"]["value"] > 0
 
 
 def test_bench_strong_scaling_configs3_rank_share():

@@ -92,8 +92,21 @@ REL_FLOOR = 1e-4       # BASELINE.json north_star: "Chamfer distance / pose erro
 # must be uniform over the instances (one-sided Kolmogorov-Smirnov test, alpha = 1e-3: "the GPU arithmetic is no worse than
 # a one-ulp input change"), per metric and pose mode, for exact f32 AND f16x3, with no outlier allowance.  K_GROSS is only
 # a tripwire for a wrong answer on a single instance (10 x the instance's own band).
+# Round 4 (VERDICT / ADVICE of round 3): the rank gate keeps only the instances outside the 1e-4 floor -- 5 to 10 of 64
+# in pose_known mode -- and could not tell the mixed mode (Jacobians ~1e-3) from the fp32-class arithmetics there.  It is
+# now one of three layers per metric:
+#   (1) `parity_stats.exchange_test` over ALL instances: mean log(deviation / largest perturbed deviation) against its
+#       Monte-Carlo null "the GPU is one more perturbed run"; the fp32-class arithmetics must pass, and as a POSITIVE
+#       CONTROL the mixed and plain-fp16 modes must be REJECTED by the very same statistic in pose_known mode;
+#   (2) the KS rank gate, asserted where it has power (its smallest attainable p is below alpha) and reported otherwise;
+#   (3) a per-instance cap: no instance beyond K_CAP x its own perturbation band in more than N_CAP_OUT metric entries,
+#       none at all beyond K_GROSS x.
+# alpha = 1e-3 per gate is a family-wise choice: 2 arithmetics x 2 modes x 2 record sets x 4 metrics = 32 gated
+# statistics per layer, so a true-null suite fails about once in 30 runs at 1e-3 and about once in 3 at 1e-2.
 ALPHA = 1e-3
 K_GROSS = 10.0
+K_CAP = 4.0
+N_CAP_OUT = 1
 _FS = {}
 
 
@@ -181,7 +194,10 @@ def test_full_batch_metric_parity(mode, precision, records):
     dev = np.abs(m_gpu - m_cpu)
     names = ("chamfer", "t_err", "r_err", "scale")
     gates = {names[k]: PS.gate(dev[:, k], pert_dev[:, :, k], floor[:, k], ALPHA) for k in range(4)}
+    exch = {names[k]: PS.exchange_test(dev[:, k], pert_dev[:, :, k]) for k in range(4)}
     gross = [(i, names[k]) for i in range(n) for k in range(4) if dev[i, k] > max(floor[i, k], K_GROSS * noise[i, k])]
+    capped = [(i, names[k], round(float(dev[i, k] / max(noise[i, k], 1e-300)), 1)) for i in range(n) for k in range(4)
+              if dev[i, k] > max(floor[i, k], K_CAP * noise[i, k])]
     lines = [f"# c2_joint full batch ({records} decoder), {n} instances x {n_iter} LM iterations, pose_{mode}, GPU {precision} "
              "vs CPU oracle",
              f"# gate per metric: inside {REL_FLOOR:g} * scale -> outright; else rank of the deviation among the {m_pert.shape[0]} "
@@ -201,17 +217,31 @@ def test_full_batch_metric_parity(mode, precision, records):
         g = gates[k]
         lines.append(f"# {k:8s}: within 1e-4 outright {g['outright']:2d} of {n}; ranked {g['ranked']:2d}: mean rank {g['mean_rank']:.2f} "
                      f"(0.5 = like a perturbed run), at the top rank {g['top_rank']}, KS+ {g['ks']:.3f}, p = {g['p']:.3f} "
+                     f"(smallest attainable {g['min_p']:.1e}: {'has power' if g['has_power'] else 'NO POWER, reported only'}) "
                      f"-> {'ok' if g['ok'] else 'FAIL'}")
+        e = exch[k]
+        lines.append(f"# {k:8s}: exchangeability over {e['n']} instances: mean log(dev / max perturbed dev) = {e['T']:.2f}, null "
+                     f"{e['null_mean']:.2f} +- {e['null_sd']:.2f} (z = {e['z']:+.1f}), one-sided p = {e['p']:.4f}")
+    lines.append(f"# beyond {K_CAP:g} x the instance's own band (allowed: {N_CAP_OUT} entry): {capped}")
     lines.append(f"# beyond {K_GROSS:g} x the instance's own band (gross-error tripwire): {gross}")
     os.makedirs("gpurun_out", exist_ok=True)
     tag = "fullsize" if records == "analytic" else records
-    with open(os.path.join("gpurun_out", f"r03_parity_{tag}_{mode}_{precision}.txt"), "w") as f:
+    with open(os.path.join("gpurun_out", f"r04_parity_{tag}_{mode}_{precision}.txt"), "w") as f:
         f.write("\n".join(lines) + "\n")
-    print("\n" + "\n".join(lines[-6:]))
+    print("\n" + "\n".join(lines[-11:]))
     if precision in ("f32", "f16x3"):          # the fp32-class arithmetics are gated; the other modes are reported
         for k in names:
-            assert gates[k]["ok"], f"{precision} pose_{mode} {k}: ranks not uniform (KS+ {gates[k]['ks']:.3f}, p {gates[k]['p']:.2e})"
+            assert exch[k]["p"] >= ALPHA, f"{precision} pose_{mode} {k}: worse than a perturbed run ({exch[k]})"
+            assert gates[k]["ok"] or not gates[k]["has_power"], \
+                f"{precision} pose_{mode} {k}: ranks not uniform (KS+ {gates[k]['ks']:.3f}, p {gates[k]['p']:.2e})"
+        assert len(capped) <= N_CAP_OUT, f"{precision} pose_{mode}: beyond {K_CAP} x the instance's own band: {capped}"
         assert not gross, f"{precision} pose_{mode}: beyond {K_GROSS} x the instance's own perturbation band: {gross}"
+    elif mode == "known" and records == "analytic":
+        # POSITIVE CONTROL: 1e-3 Jacobians (mixed mode) and fp16-class arithmetic must be told from fp32-class by the same
+        # statistic that passes f32 / f16x3 above.  (With a free pose the 200-iteration map is chaotic at this size and no
+        # statistic of the final state can see them: DESIGN.md section 2.)
+        assert exch["chamfer"]["p"] < ALPHA and exch["scale"]["p"] < ALPHA, \
+            f"the gate cannot tell {precision} from fp32-class: {exch['chamfer']}, {exch['scale']}"
 
 
 @pytest.mark.parametrize("records", ["analytic", "trained"])
@@ -264,12 +294,22 @@ def test_fullsize_against_reference_records(mode, precision, records):
                    f"(reference's own noise median {np.median(pert_ref.max(axis=0)[:, 0] / m_ref[0][:, 0]):.2e}); Chamfer: outright "
                    f"{g_cd['outright']}/{nI}, ranked mean {g_cd['mean_rank']:.2f} p {g_cd['p']:.3f}; pose metrics: outright "
                    f"{g_pose['outright']}/{3 * nI}, ranked mean {g_pose['mean_rank']:.2f} p {g_pose['p']:.3f}")
-        assert g_cd["ok"] and g_pose["ok"], out[-1]          # (no gross-error cap here: a max-of-FOUR band is too coarse for one)
+        e_cd = PS.exchange_test(dev[:, 0], pert_ref[:, :, 0])
+        # band of the cap: the reference's own K perturbed deviations AND the oracle's for the same perturbations (a max of
+        # two or four draws alone is too coarse a band for a per-instance cap)
+        band = np.maximum(pert_ref.max(axis=0), pert_orc.max(axis=0))
+        over = [(int(ids[i]), k) for i in range(nI) for k in range(4) if dev[i, k] > max(floor[i, k], K_CAP * band[i, k])]
+        out.append(f"        Chamfer KS gate: smallest attainable p {g_cd['min_p']:.1e} ({'has power' if g_cd['has_power'] else 'NO power at alpha = %g: the exchangeability test and the cap carry this gate' % ALPHA}); "
+                   f"exchangeability p = {e_cd['p']:.4f} (mean log-ratio {e_cd['T']:.2f}, null {e_cd['null_mean']:.2f} +- {e_cd['null_sd']:.2f}); "
+                   f"beyond {K_CAP:g} x max(reference band, oracle band): {over}")
+        assert (g_cd["ok"] or not g_cd["has_power"]) and (g_pose["ok"] or not g_pose["has_power"]), out[-2]
+        assert e_cd["p"] >= ALPHA, out[-1]
+        assert len(over) <= N_CAP_OUT, out[-1]
     tiny = 1e-9 * m_ref[0][:, 0]                        # Chamfer noise of the instances, whatever its size
     ratio = float(np.exp(np.mean(np.log((pert_orc.max(axis=0)[:, 0] + tiny) / (pert_ref.max(axis=0)[:, 0] + tiny)))))
     out.append(f"oracle Chamfer noise / reference Chamfer noise over the same {K} perturbations (geometric mean, {nI} instances): {ratio:.2f}")
     os.makedirs("gpurun_out", exist_ok=True)
-    with open(os.path.join("gpurun_out", f"r03_parity_vs_reference_{records}_{mode}_{precision}.txt"), "w") as f:
+    with open(os.path.join("gpurun_out", f"r04_parity_vs_reference_{records}_{mode}_{precision}.txt"), "w") as f:
         f.write("\n".join(out) + "\n")
     print("\n" + "\n".join(out))
     lim = 2.0 if K >= 4 else 3.0
@@ -413,7 +453,7 @@ def test_wellconditioned_free_pose_parity(precision):
     lines.append(f"# largest fraction of the 1e-4 tolerance used: GPU {np.max(dev / tol):.2f} (per metric {np.round((dev / tol).max(axis=0), 2).tolist()}), "
                  f"oracle's own perturbed runs {np.max(noise / tol):.2f}")
     os.makedirs("gpurun_out", exist_ok=True)
-    with open(os.path.join("gpurun_out", f"r03_parity_wellconditioned_free_{precision}.txt"), "w") as f:
+    with open(os.path.join("gpurun_out", f"r04_parity_wellconditioned_free_{precision}.txt"), "w") as f:
         f.write("\n".join(lines) + "\n")
     print("\n" + lines[-1])
     # ... and against the ACTUAL reference loop on the first instances (tests/golden/make_reference_records.py --case wc:
@@ -427,46 +467,62 @@ def test_wellconditioned_free_pose_parity(precision):
     line = (f"# vs the ACTUAL reference on {len(pos)} instances, fraction of the 1e-4 tolerance used: oracle {np.max(d_or / tol[pos]):.2f}, "
             f"GPU {precision} {np.max(d_gr / tol[pos]):.2f}, the reference's own perturbed run {np.max(d_rr / tol[pos]):.2f}")
     print(line)
-    with open(os.path.join("gpurun_out", f"r03_parity_wellconditioned_free_{precision}.txt"), "a") as f:
+    with open(os.path.join("gpurun_out", f"r04_parity_wellconditioned_free_{precision}.txt"), "a") as f:
         f.write(line + "\n")
     assert np.all(d_or <= tol[pos]) and np.all(d_rr <= tol[pos])     # oracle == reference, and the reference is stable here
     if precision in ("f32", "f16x3"):
         assert np.all(dev <= tol), [(int(inp["inst_ids"][i]), (dev[i] / tol[i]).round(2).tolist()) for i in range(n) if np.any(dev[i] > tol[i])]
         assert np.all(d_gr <= tol[pos])
+    else:
+        # POSITIVE CONTROL: the outright 1e-4 gate must reject the arithmetics that are not fp32-class (measured: the mixed
+        # mode uses 1.4 x the tolerance, plain fp16 320 x)
+        assert not np.all(dev <= tol), f"{precision} passes the fp32-class gate: the gate has no power"
 
 
-def test_shape_only_fullsize_state_parity(precision):
+@pytest.mark.parametrize("npts", [1024, 2048])
+def test_shape_only_fullsize_state_parity(precision, npts):
     """The shape-only loop (`shape_opt_deepsdf`, bench.py's `c2_sdf` line) at full size -- L = 256, 200 forced iterations,
-    16 instances of the C2 fixture (their 1024 surface points) -- is well conditioned, so parity is asserted at STATE level
-    and outright: the HIP latent against the CPU oracle AND against the records of the ACTUAL reference loop
-    (tests/golden/c2_sdf_fullsize_records.npz: oracle == reference to 1e-6 there), to 5e-5 / 1e-5 of the latent's size in
-    the two fp32-class arithmetics (the mixed and fp16 modes land at 1e-4 and 1e-3: reported); the pose must come back
-    untouched."""
+    16 instances -- is well conditioned, so parity is asserted at STATE level and outright: the HIP latent against the CPU
+    oracle AND against the records of the ACTUAL reference loop (oracle == reference to 1e-6 there), to 5e-5 / 1e-5 of the
+    latent's size in the two fp32-class arithmetics; the pose must come back untouched.
+    npts = 1024: the C2 fixture's surface points (tests/golden/c2_sdf_fullsize_records.npz); npts = 2048: the instances of
+    the `c2_sdf` BENCH workload itself, BASELINE.json's literal "2048 pts/instance" (c2_sdf2048_inputs.npz / _records.npz,
+    `make_sdf_records.py 2048`).  POSITIVE CONTROL: the mixed and fp16 modes must FAIL the fp32-class bound (they land at
+    1e-4 and 1e-3)."""
     import os
     from golden_util import GOLDEN_DIR
     from hortimapping_amd import optimizer as HO, workloads as W
     from hortimapping_amd.decoder import DecoderWeights
     fs = fullsize_fixture("analytic")
-    rec = np.load(os.path.join(GOLDEN_DIR, "c2_sdf_fullsize_records.npz"))
+    rec = np.load(os.path.join(GOLDEN_DIR, "c2_sdf_fullsize_records.npz" if npts == 1024 else f"c2_sdf{npts}_records.npz"))
     zo, zr = rec["orc_latent"][0], rec["ref_latent"][0]
     n = zo.shape[0]
     dec = DecoderWeights.from_params(fs["params"])
     dec.set_precision(precision)
-    insts = fullsize_instances(False, "analytic")[:n]
+    if npts == 1024:
+        insts = fullsize_instances(False, "analytic")[:n]
+    else:
+        inp = np.load(os.path.join(GOLDEN_DIR, f"c2_sdf{npts}_inputs.npz"))
+        t = torch.from_numpy
+        assert inp["points_w"].shape[1:] == (npts, 3)
+        insts = [HO.Instance(t(inp["latent0"][i].copy()), t(inp["T_ow0"][i].copy()), t(inp["points_w"][i]), None, 0.08, True)
+                 for i in range(n)]
     res = HO.optimize_batch(dec, W.c2_opt_cfg(max_iter=200), insts, shape_only=True)
     assert all(r.iter_count == 200 and r.status == 8 for r in res)
     z = np.stack([r.latent.numpy() for r in res])
     sc = np.abs(zo).max(axis=1)
     d_o = np.abs(z - zo).max(axis=1) / sc
     d_r = np.abs(z[:zr.shape[0]] - zr).max(axis=1) / sc[:zr.shape[0]]
-    print(f"\nshape-only, {precision}: max |z_gpu - z_oracle| / max|z|: median {np.median(d_o):.2e} max {d_o.max():.2e}; vs the reference: max {d_r.max():.2e}")
+    print(f"\nshape-only, {npts} points, {precision}: max |z_gpu - z_oracle| / max|z|: median {np.median(d_o):.2e} max {d_o.max():.2e}; vs the reference: max {d_r.max():.2e}")
     os.makedirs("gpurun_out", exist_ok=True)
-    with open(os.path.join("gpurun_out", f"r03_parity_shape_only_{precision}.txt"), "w") as f:
-        f.write(f"# shape_opt_deepsdf, 16 instances x 200 iterations, L = 256, GPU {precision}: relative latent deviation per instance\n"
+    with open(os.path.join("gpurun_out", f"r04_parity_shape_only_{npts}_{precision}.txt"), "w") as f:
+        f.write(f"# shape_opt_deepsdf, 16 instances x 200 iterations, L = 256, {npts} surface points, GPU {precision}: relative latent deviation per instance\n"
                 "# id  vs_oracle  vs_reference(first 8)\n" +
                 "\n".join(f"{i:2d} {d_o[i]:.2e} {(d_r[i] if i < len(d_r) else float('nan')):.2e}" for i in range(n)) + "\n")
     for inst, r in zip(insts, res):
         assert torch.equal(r.T_ow, inst.T_ow)
     if precision in ("f32", "f16x3"):
-        # measured: vs the reference <= 2.2e-6 (8 instances), vs the oracle median 2e-6, max 1.9e-5 (one of 16)
+        # measured (1024 points): vs the reference <= 2.2e-6 (8 instances), vs the oracle median 2e-6, max 1.9e-5 (one of 16)
         assert d_o.max() < 5e-5 and d_r.max() < 1e-5
+    else:
+        assert d_o.max() > 5e-5 or d_r.max() > 1e-5, f"{precision} passes the fp32-class bound: the gate has no power"

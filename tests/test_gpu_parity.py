@@ -356,3 +356,52 @@ def test_f16x3_activation_overflow_is_reported():
     for prec in ("f16x3", "f16x3f_f16b"):
         assert out[prec].status & 32 and out[prec].iter_count < 3
         assert torch.equal(out[prec].latent, inst.latent)        # state left untouched by the failed step
+
+
+def test_f16x3_overflow_is_retried_in_exact_f32():
+    """Twin of the test above with `retry_f32` (what the drop-in `Optimizer` does): in a mixed batch the instance whose
+    activations leave the fp16 range comes back as the PURE exact-fp32 run of that instance, bit for bit (latent, pose,
+    iteration count, status) and flagged; the in-range instances keep their f16x3 results; the decoder's precision
+    setting is restored."""
+    from hortimapping_amd import optimizer as HO, synthetic as S, workloads as W
+    from hortimapping_amd.decoder import DecoderWeights
+    p = S.make_synthetic_decoder(32, seed=3, r0=0.04, aniso=(1.0, 0.75, 1.3))
+    big = {k: (v.copy() if hasattr(v, "copy") else v) for k, v in p.items()}
+    big["lin1.weight_g"] = big["lin1.weight_g"] * 4.0e6
+    big["lin2.weight_g"] = big["lin2.weight_g"] / 4.0e6
+    Ws, bs = S.fold_weight_norm(p)
+    insts = [W.to_instance(S.make_instance(Ws, bs, 32, i, n_pts=256, n_frames=1, n_fg=16, n_bg=16), pose_known=True) for i in (1, 2)]
+    opt = W.c2_opt_cfg(max_iter=3)
+    dec = DecoderWeights.from_params(big).set_precision("f32")
+    pure = HO.optimize_batch(dec, opt, insts)
+    assert all(r.status == 8 and r.iter_count == 3 and not r.retried_f32 for r in pure)
+    dec.set_precision("f16x3")
+    rep = HO.optimize_batch(dec, opt, insts)                          # reported, not retried
+    assert all(r.status & 32 for r in rep)
+    got = HO.optimize_batch(dec, opt, insts, retry_f32=True)
+    assert dec.precision == "f16x3"
+    for a, b in zip(got, pure):
+        assert a.retried_f32 and a.status == b.status and a.iter_count == b.iter_count
+        assert torch.equal(a.latent, b.latent) and torch.equal(a.T_ow, b.T_ow)
+    # a decoder inside the fp16 range: nothing is retried, results are the f16x3 ones
+    ok = DecoderWeights.from_params(p).set_precision("f16x3")
+    r1 = HO.optimize_batch(ok, opt, insts)
+    r2 = HO.optimize_batch(ok, opt, insts, retry_f32=True)
+    assert all((not b.retried_f32) and torch.equal(a.latent, b.latent) and torch.equal(a.T_ow, b.T_ow) for a, b in zip(r1, r2))
+    # the drop-in class built from a torch module defaults to f16x3 and retries by itself
+    import os
+    if not os.environ.get("HM_PRECISION"):
+        class Net(torch.nn.Module):                       # the reference passes an nn.Module (optimizer.py:17)
+            def __init__(self):
+                super().__init__()
+                for l, (o_, i_) in enumerate(S.layer_shapes(32)):
+                    lin = torch.nn.Linear(i_, o_)
+                    setattr(self, f"lin{l}", torch.nn.utils.weight_norm(lin) if l < 8 else lin)
+        net = Net()
+        net.load_state_dict({k: torch.from_numpy(np.asarray(v).copy()) for k, v in big.items() if k not in ("latent_dim", "hidden")}, strict=True)
+        o = HO.Optimizer({"device": "cuda", "opt": opt, "vis": {}}, net)
+        assert o.decoder.precision == "f16x3"
+        lat = insts[0].latent.clone()
+        z, T, n = o.shape_pose_joint_opt(lat, insts[0].T_ow, insts[0].render_data, insts[0].points_w, insts[0].cube_radius, None, True)
+        assert n == 3 and torch.equal(z.cpu(), pure[0].latent) and torch.equal(T.cpu(), pure[0].T_ow)
+
