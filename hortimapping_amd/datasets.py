@@ -298,3 +298,22 @@ def _fib(n):
     phi = np.arccos(1 - 2 * i / n)
     th = np.pi * (1 + 5 ** 0.5) * i
     return np.stack([np.cos(th) * np.sin(phi), np.sin(th) * np.sin(phi), np.cos(phi)], 1)
+
+
+def dump_jobs(path, named_instances, results, opt_cfg, precision):
+    """Test aid of the entry-point scripts (`--dump-jobs`): the prepared per-instance inputs exactly as they went into
+    `Optimizer.optimize_batch`, and its raw results, so that tests/test_gpu_cli.py can run the CPU oracle on the SAME
+    inputs and compare what the scripts wrote (poses, kept / skipped instances, iteration counts, metrics)."""
+    import torch
+    jobs = []
+    for (name, inst), res in zip(named_instances, results):
+        rd = inst.render_data
+        jobs.append({"name": name, "latent0": inst.latent.detach().cpu().clone(), "T_ow0": inst.T_ow.detach().cpu().clone(),
+                     "points_w": inst.points_w.detach().cpu().clone(), "cube_radius": float(inst.cube_radius),
+                     "pose_known": bool(inst.pose_known),
+                     "render_data": None if rd is None else {k: [torch.as_tensor(a).detach().cpu().clone() for a in rd[k]]
+                                                             for k in ("T_wc", "rays_fg", "rays_bg", "depth_fg", "depth_bg")},
+                     "latent": res.latent.clone(), "T_ow": res.T_ow.clone(), "iter_count": int(res.iter_count),
+                     "status": int(res.status), "retried_f32": bool(getattr(res, "retried_f32", False))})
+    torch.save({"jobs": jobs, "opt": opt_cfg, "precision": precision}, path)
+

@@ -29,7 +29,9 @@ from test_wild_completion import load_decoder
 @click.option("--config", "-c", type=str, help="path to the config file (.yaml)",
               default=os.path.join(os.path.dirname(os.path.abspath(__file__)),
                                    "configs/shape_completion_challenge_pepper.yaml"))
-def main(config):
+@click.option("--dump-jobs", type=str, default="", hidden=True,
+              help="(tests) torch.save the prepared per-instance inputs and the raw optimiser results here")
+def main(config, dump_jobs):
     np.random.seed(42)
     torch.manual_seed(42)
     cfg = yaml.safe_load(open(config))
@@ -40,6 +42,10 @@ def main(config):
     voxels_dim = int(2 * object_radius_max_m * 1e3 / float(cfg["vis"]["mc_res_mm"]))
     deepsdf_baseline = cfg["baseline_name"] == "DeepSDF"
     mesh_extractor = MeshExtractor(decoder, code_len=code_len, voxels_dim=voxels_dim, cube_radius=object_radius_max_m)
+    if not os.environ.get("HM_PRECISION"):
+        # fp32-class arithmetic at three times the speed of exact fp32; an instance whose activations leave the fp16 range
+        # is rerun in exact fp32 by the Optimizer itself (hortimapping_amd/optimizer.py: retry_f32)
+        decoder.set_precision("f16x3")
     opt = Optimizer(cfg, decoder, mesh_extractor, None)
     cd_metric = ChamferDistance(backend="gpu")                            # 1,000,000-point clouds: hm_nn_distance
     pr_metric = PrecisionRecall(min_t=0.001, max_t=0.01, num=100, backend="gpu")          # :83
@@ -82,6 +88,8 @@ def main(config):
     results = opt.optimize_batch([j[2] for j in jobs], shape_only=deepsdf_baseline) if jobs else []
     torch.cuda.synchronize()
     t_total = time.time() - t0
+    if dump_jobs:                     # tests/test_gpu_cli.py feeds exactly these inputs to the CPU oracle
+        DS.dump_jobs(dump_jobs, [(j[0], j[2]) for j in jobs], results, cfg["opt"], opt.decoder.precision)
     iters = []
     for (fid, gt, _), res in zip(jobs, results):
         T_wo = inv(res.T_ow.numpy().astype(np.float64))

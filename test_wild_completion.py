@@ -46,7 +46,9 @@ def load_decoder(cfg):
 @click.command()
 @click.option("--config", "-c", type=str, help="path to the config file (.yaml)",
               default=os.path.join(os.path.dirname(os.path.abspath(__file__)), "configs/wild_pepper.yaml"))
-def main(config):
+@click.option("--dump-jobs", type=str, default="", hidden=True,
+              help="(tests) torch.save the prepared per-instance inputs and the raw optimiser results here")
+def main(config, dump_jobs):
     np.random.seed(42)                                                  # set_random_seed(42), utils.py:638-641
     torch.manual_seed(42)
     cfg = yaml.safe_load(open(config))
@@ -69,6 +71,10 @@ def main(config):
     print("Loaded %d frames, image size %s" % (len(frames["id"]), img_size))
 
     mesh_extractor = MeshExtractor(decoder, code_len=code_len, voxels_dim=voxels_dim, cube_radius=object_radius_max_m)
+    if not os.environ.get("HM_PRECISION"):
+        # fp32-class arithmetic at three times the speed of exact fp32; an instance whose activations leave the fp16 range
+        # is rerun in exact fp32 by the Optimizer itself (hortimapping_amd/optimizer.py: retry_f32)
+        decoder.set_precision("f16x3")
     opt = Optimizer(cfg, decoder, mesh_extractor, None)
 
     # instance loop of the reference (:133), split in two so that the image scans of get_render_data run on the GPU for
@@ -126,6 +132,8 @@ def main(config):
         jobs.append((submap_name, submap_id, pts, inst))
     print("Optimising %d fruit instances in one batch" % len(jobs))
     results = opt.optimize_batch([j[3] for j in jobs]) if jobs else []
+    if dump_jobs:                     # tests/test_gpu_cli.py feeds exactly these inputs to the CPU oracle
+        DS.dump_jobs(dump_jobs, [(j[0], j[3]) for j in jobs], results, cfg["opt"], opt.decoder.precision)
 
     kept = 0
     for (submap_name, submap_id, pts, _), res in zip(jobs, results):
