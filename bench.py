@@ -252,6 +252,9 @@ def parse_args(argv=None):
     ap.add_argument("--shipped-only", default="", choices=[""] + sorted(SHIPPED),
                     help="run ONLY this shipped configuration (L = 32, real render block, early exits) and print its object")
     ap.add_argument("--no-shipped", action="store_true", help="skip the configs[0]/[2]/[4] secondary objects")
+    ap.add_argument("--groups", type=int, default=0,
+                    help="instance groups per hm_optimize_batch call (internal streams): 0 = automatic (2 from 16 instances on), "
+                         "1 = one stream (the schedule of rounds 1-3; use it under rocprofv3 for un-overlapped kernel durations)")
     ap.add_argument("--split-render", action="store_true", help=argparse.SUPPRESS)   # A/B: round-2 launch sequence (hm_debug_split_render)
     ap.add_argument("--stub-cpu", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--share-gpu", action="store_true", help=argparse.SUPPRESS)   # tests: N ranks on ONE GPU over gloo
@@ -365,6 +368,8 @@ def main(argv=None, emit=True):
         lib = _lib.lib()
         if args.split_render:
             lib.hm_debug_split_render(1)
+        lib.hm_workspace_set_groups.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        lib.hm_workspace_set_groups(ws.handle, args.groups)
         lib.hm_workspace_profile.argtypes = [ctypes.c_void_p, ctypes.c_int]
         lib.hm_workspace_profile_read.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double),
                                                   ctypes.POINTER(ctypes.c_longlong)]
@@ -415,7 +420,6 @@ def main(argv=None, emit=True):
         for _ in range(warmup):
             step()
         fence()
-        profile_on(True)
         t0 = time.perf_counter()
         for _ in range(steps):
             allrec = step()
@@ -425,6 +429,14 @@ def main(argv=None, emit=True):
             tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             dt = float(tmax.item())
+        # Duration of the dominant launch: ONE extra, untimed step with HIP events around every such launch.  With the
+        # events on, hm_optimize_batch runs the batch on ONE stream (in the timed steps above it runs as two instance
+        # groups on their own streams, whose launches overlap: a per-launch duration would then include the other groups'
+        # kernels).  So `roofline` prices the kernel in its un-overlapped schedule -- the one the committed rocprofv3
+        # stats (bench.py --groups 1) show -- and `roofline.step` the whole step as timed.
+        profile_on(True)
+        step()
+        fence()
         ms_tot, n_launch = profile_read()
         profile_on(False)
         return dt, ms_tot, n_launch, allrec
@@ -462,6 +474,7 @@ def main(argv=None, emit=True):
              "traffic": traffic, "traffic_source": tsrc, "algorithmic_bytes_per_launch": alg_bytes,
              "traffic_over_algorithmic": (round(traffic / alg_bytes, 2) if traffic else None),
              "launches": n_launch, "avg_launch_ms": round(avg_ms, 4),
+             "timing": "HIP events around every such launch in one extra untimed step on ONE stream (un-overlapped schedule)",
              "algorithmic_flop_per_launch": int(flops),
              "queries_per_launch": {"forward_backward": int(q), "forward_only": int(round(q_fwd))}}
         if busy is not None:                      # matrix-pipe utilisation (all MFMA issued, incl. the 3 passes of f16x3)
@@ -533,6 +546,8 @@ def main(argv=None, emit=True):
                                     "trained on a synthetic pepper family (scripts/train_synthetic_deepsdf.py, "
                                     "tests/golden/trained_decoder_L256.npz)"),
                 "parallelism": f"instances sharded over {world} GPU(s), one RCCL all-gather of results per step",
+                "scheduling": ("one stream per call" if args.groups == 1 else
+                               "each call runs its instances as two groups on internal HIP streams, started one main launch apart (hm_optimize_batch)"),
             },
         }
         if share:
@@ -540,7 +555,7 @@ def main(argv=None, emit=True):
         if stub:
             out["stub"] = "rank logic only (gloo, CPU stand-in for the GPU optimisation): NOT a measurement"
         else:
-            out["roofline"] = roofline(args.precision, ms_tot, n_launch, counts, args.steps)
+            out["roofline"] = roofline(args.precision, ms_tot, n_launch, counts, 1)
             out["roofline"]["step"] = step_roofline(args.precision, dt / args.steps * 1e3, counts)
     if not stub and not args.no_exact and world == 1 and not strong:
         # the same job in the other decoder arithmetics, one timed step each, for reference next to the primary line
@@ -553,7 +568,7 @@ def main(argv=None, emit=True):
             l2, T2, _, _ = D.unpack_records(allrec2.cpu(), L)
             out[key] = {"value": round(n_total * k2 / dt2, 3), "unit": "instances/s", "steps": k2, "dtype": other,
                         "dtype_note": PRECISIONS[other][2], "ms_per_step": round(dt2 / k2 * 1e3, 3),
-                        "roofline": roofline(other, ms2, nl2, cnt2, k2),
+                        "roofline": roofline(other, ms2, nl2, cnt2, 1),
                         "max_abs_latent_diff_vs_primary": float((l2 - lat).abs().max()),
                         "max_abs_T_diff_vs_primary": float((T2 - T).abs().max()),
                         "diff_note": "free-pose 200-iteration trajectories amplify rounding noise; per-instance parity of "
@@ -563,7 +578,7 @@ def main(argv=None, emit=True):
         # the same job on TRAINED decoder weights (dense layers instead of the near-identity analytic ones: different
         # operand statistics for the matrix cores and the socket power limit), one timed step
         o2 = main(["--steps", "1", "--warmup", "1", "--iters", str(args.iters), "--decoder", "trained", "--precision",
-                   args.precision, "--no-exact", "--no-cpu-baseline"], emit=False)
+                   args.precision, "--no-exact", "--no-cpu-baseline", "--groups", str(args.groups)], emit=False)
         out["trained_decoder"] = {"value": o2["value"], "unit": o2["unit"], "steps": 1, "dtype": o2["dtype"],
                                   "ms_per_step": o2["ms_per_step"], "roofline": o2["roofline"],
                                   "decoder_weights": o2["config"]["decoder_weights"],
@@ -571,19 +586,19 @@ def main(argv=None, emit=True):
         # the same job with 256 instances resident per GPU (the chunk size of configs[3]): the ragged last tile rounds of
         # the render-chain launches and the per-instance solve amortise over more instances
         o3 = main(["--steps", "1", "--warmup", "1", "--iters", str(args.iters), "--total", "256", "--batch", "256", "--precision",
-                   args.precision, "--no-exact", "--no-cpu-baseline"], emit=False)
+                   args.precision, "--no-exact", "--no-cpu-baseline", "--groups", str(args.groups)], emit=False)
         out["batch_256"] = {"value": o3["value"], "unit": o3["unit"], "steps": 1, "dtype": o3["dtype"],
                             "ms_per_step": o3["ms_per_step"], "instances_per_gpu": 256,
                             "note": "64 distinct synthetic peppers replicated cyclically; not the BASELINE configuration"}
         # SURVEY.md 8d "run twice": C2-sdf = the shape-only loop (shape_opt_deepsdf) on 2048 surface points per instance
         o4 = main(["--steps", "3", "--warmup", "1", "--iters", str(args.iters), "--workload", "c2_sdf", "--precision",
-                   args.precision, "--no-exact", "--no-cpu-baseline"], emit=False)
+                   args.precision, "--no-exact", "--no-cpu-baseline", "--groups", str(args.groups)], emit=False)
         out["c2_sdf"] = {"value": o4["value"], "unit": o4["unit"], "steps": 3, "dtype": o4["dtype"],
                          "ms_per_step": o4["ms_per_step"], "workload": o4["config"]["workload"], "roofline": o4["roofline"]}
         # BASELINE.json configs[3] as ONE rank of eight sees it: 512 of the 4096 instances, two chunks of 256 through one
         # workspace (the strong-scaling job is `bench.py --gpus 8 --total 4096`)
         o5 = main(["--steps", "1", "--warmup", "1", "--iters", str(args.iters), "--total", "512", "--batch", "256",
-                   "--precision", args.precision, "--no-exact", "--no-cpu-baseline"], emit=False)
+                   "--precision", args.precision, "--no-exact", "--no-cpu-baseline", "--groups", str(args.groups)], emit=False)
         out["configs3_rank_share"] = {"value": o5["value"], "unit": o5["unit"], "steps": 1, "dtype": o5["dtype"],
                                       "ms_per_step": o5["ms_per_step"], "instances": 512, "chunk": 256,
                                       "roofline_step": o5["roofline"]["step"],

@@ -40,13 +40,19 @@ struct hm_workspace_s {
   // early stop of the launch loop: per-iteration count of still-active instances, copied to pinned host memory and
   // polled (never waited for) a few iterations later
   static constexpr int N_ACT = 8;
-  int* d_act_count;               // [N_ACT]
-  int* h_act_count;               // [N_ACT], pinned
-  hipEvent_t ev_act[N_ACT];
+  static constexpr int G_MAX = 4;  // instance groups of one call, each on its own stream (see hm_optimize_batch)
+  int* d_act_count;               // [G_MAX][N_ACT]
+  int* h_act_count;               // [G_MAX][N_ACT], pinned
+  hipEvent_t ev_act[G_MAX][N_ACT];
   bool act_ready;
   // optional work counters (measurement): sums over every instance-iteration since the last enable
   int count_on;
-  unsigned long long* d_counters; // [N_COUNTER]
+  unsigned long long* d_counters; // [G_MAX][N_COUNTER]: one set per instance group (they run concurrently), summed on read
+  // instance groups: internal streams + fork / join events; 0 = automatic group count
+  hipStream_t gstream[G_MAX];
+  hipEvent_t ev_fork, ev_join[G_MAX], ev_stagger[G_MAX];
+  int n_gres;                     // group resources created so far (all or none)
+  int groups_override;
   // test / A-B switches, scoped to THIS workspace: the override set by hm_workspace_set_debug (-1 = follow the process
   // default of hm_debug_split_render / hm_debug_force_direct_solve) and the value snapshotted when an entry point is
   // called -- one call never sees a switch change under it (a mask-less forward paired with a mask-reading backward)
@@ -63,59 +69,75 @@ enum { CNT_INST_ITER = 0, CNT_SDF_QUERIES, CNT_RAY_FWD, CNT_RAY_JAC, CNT_RAYS, N
 
 namespace {
 
+// Every workspace buffer is laid out [B][per-instance part], so the workspace of an instance GROUP [b0, b0 + nb) is a VIEW
+// of the parent's: the same struct with every pointer moved by b0 x its per-instance stride (no second allocation).
+// carve() therefore registers each buffer with its per-instance size and runs in three modes.
 struct Carver {
+  enum Mode { SIZE, CARVE, VIEW } mode = SIZE;
   size_t off = 0;
   char* base = nullptr;
+  int b0 = 0, g = 0;             // VIEW: first instance of the group, group index
   template <typename T>
-  T* take(size_t n) {
+  void take(T*& field, size_t per_inst, size_t B) {
+    if (mode == VIEW) { if (field) field += (size_t)b0 * per_inst; return; }
     off = (off + 255) & ~size_t(255);
-    T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
-    off += n * sizeof(T);
-    return p;
+    field = base ? reinterpret_cast<T*>(base + off) : nullptr;
+    off += B * per_inst * sizeof(T);
+  }
+  template <typename T>
+  void take_group(T*& field, size_t n) {                 // one copy per instance group
+    if (mode == VIEW) { if (field) field += (size_t)g * n; return; }
+    off = (off + 255) & ~size_t(255);
+    field = base ? reinterpret_cast<T*>(base + off) : nullptr;
+    off += (size_t)hm_workspace_s::G_MAX * n * sizeof(T);
   }
 };
 
 int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
 void carve(hm_workspace_s* w, Carver& c) {
-  const int B = w->lim.max_batch, F = w->lim.max_frames, R = w->lim.max_rays;
-  const size_t nray = (size_t)F * R;
-  w->d_act_count = c.take<int>(hm_workspace_s::N_ACT);
-  w->d_counters = c.take<unsigned long long>(N_COUNTER);
-  w->c0 = c.take<float>((size_t)B * HID);
-  w->c4 = c.take<float>((size_t)B * HID);
-  w->ptsS = c.take<float>((size_t)B * w->nS_stride * 4);
-  w->JS = c.take<float>((size_t)B * w->nS_stride * w->ldJ);
-  w->yS = c.take<float>((size_t)B * w->nS_stride);
-  w->Hext = c.take<float>((size_t)B * w->ldJ * w->ldJ);
-  w->Lfac = c.take<float>((size_t)B * 288 * 288);
-  w->active = c.take<int>(B);
+  const size_t B = w->lim.max_batch, F = w->lim.max_frames, R = w->lim.max_rays;
+  const size_t nray = F * R, nS = w->nS_stride, nR = w->nR_stride, nG = w->nG_stride, ldJ = w->ldJ;
+  c.take_group(w->d_act_count, hm_workspace_s::N_ACT);
+  c.take_group(w->d_counters, N_COUNTER);
+  c.take(w->c0, HID, B);
+  c.take(w->c4, HID, B);
+  c.take(w->ptsS, nS * 4, B);
+  c.take(w->JS, nS * ldJ, B);
+  c.take(w->yS, nS, B);
+  c.take(w->Hext, ldJ * ldJ, B);
+  c.take(w->Lfac, (size_t)288 * 288, B);
+  c.take(w->active, 1, B);
   RenderBuffers& rb = w->rb;
-  rb.frame = c.take<float>((size_t)B * F * 16);
-  rb.valid_count = c.take<int>((size_t)B * F);
-  rb.nRq = c.take<int>(B);
-  rb.nflag = c.take<int>(B);
-  rb.status = nullptr;
-  rb.ptsR = c.take<float>((size_t)B * w->nR_stride * 4);
-  rb.ptsRc = c.take<float>((size_t)B * w->nR_stride * 4);
-  rb.cpos = c.take<int>((size_t)B * w->nR_stride);
-  rb.sdfR = c.take<float>((size_t)B * w->nR_stride);
-  rb.keepcnt = c.take<int>(B * nray);
-  rb.keepmask = c.take<unsigned long long>(B * nray);
-  rb.res_d = c.take<float>(B * nray);
-  rb.res_m = c.take<float>(B * nray);
-  rb.coef = c.take<float>((size_t)B * w->nR_stride * 2);
-  rb.ray_off = c.take<int>(B * nray);
-  rb.ray_row = c.take<int>(B * nray);
-  rb.nG = c.take<int>(B);
-  rb.V = c.take<int>(B);
-  rb.ptsG = c.take<float>((size_t)B * w->nG_stride * 4);
-  rb.coefG = c.take<float>((size_t)B * w->nG_stride * 2);
-  rb.JG = c.take<float>((size_t)B * w->nG_stride * w->ldJ);
-  rb.yG = c.take<float>((size_t)B * w->nG_stride);
-  rb.srcG = c.take<int>((size_t)B * w->nG_stride);
-  rb.maskR = w->d_maskR;          // separate, lazy allocation (ensure_masks)
-  rb.JR = c.take<float>((size_t)B * 2 * nray * w->ldJ);
+  c.take(rb.frame, F * 16, B);
+  c.take(rb.valid_count, F, B);
+  c.take(rb.nRq, 1, B);
+  c.take(rb.nflag, 1, B);
+  if (c.mode != Carver::VIEW) rb.status = nullptr;
+  c.take(rb.ptsR, nR * 4, B);
+  c.take(rb.ptsRc, nR * 4, B);
+  c.take(rb.cpos, nR, B);
+  c.take(rb.sdfR, nR, B);
+  c.take(rb.keepcnt, nray, B);
+  c.take(rb.keepmask, nray, B);
+  c.take(rb.res_d, nray, B);
+  c.take(rb.res_m, nray, B);
+  c.take(rb.coef, nR * 2, B);
+  c.take(rb.ray_off, nray, B);
+  c.take(rb.ray_row, nray, B);
+  c.take(rb.nG, 1, B);
+  c.take(rb.V, 1, B);
+  c.take(rb.ptsG, nG * 4, B);
+  c.take(rb.coefG, nG * 2, B);
+  c.take(rb.JG, nG * ldJ, B);
+  c.take(rb.yG, nG, B);
+  c.take(rb.srcG, nG, B);
+  c.take(rb.JR, 2 * nray * ldJ, B);
+  // ReLU masks of the f16x3 forward pass over the ray samples: a separate, lazy allocation (begin_call)
+  if (c.mode == Carver::VIEW) {
+    if (w->d_maskR) w->d_maskR = static_cast<char*>(w->d_maskR) + (size_t)c.b0 * (nR / TQ) * 8 * 512 * sizeof(unsigned long long);
+  }
+  rb.maskR = w->d_maskR;
   rb.nR_stride = w->nR_stride;
   rb.nG_stride = w->nG_stride;
 }
@@ -318,6 +340,7 @@ extern "C" int hm_workspace_create(hm_decoder_s* dec, const hm_limits* lim, hm_w
   w->nR_stride = round_up(w->nray * w->lim.max_samples, TQ);
   const int cap = lim->max_grad_samples > 0 ? lim->max_grad_samples : w->nray * w->lim.max_samples;
   w->nG_stride = round_up(cap, TQ);
+  w->n_gres = 0; w->groups_override = 0;
   Carver size_pass;
   carve(w, size_pass);
   w->blob_bytes = size_pass.off + 256;
@@ -326,22 +349,25 @@ extern "C" int hm_workspace_create(hm_decoder_s* dec, const hm_limits* lim, hm_w
   e = hipMemset(w->d_blob, 0, w->blob_bytes);
   if (e != hipSuccess) { hm_set_error("hipMemset failed: %s", hipGetErrorString(e)); (void)hipFree(w->d_blob); delete w; return -2; }
   Carver c;
+  c.mode = Carver::CARVE;
   c.base = static_cast<char*>(w->d_blob);
   carve(w, c);
   w->h_act_count = nullptr;
   w->act_ready = false;
-  e = hipHostMalloc(reinterpret_cast<void**>(&w->h_act_count), hm_workspace_s::N_ACT * sizeof(int), hipHostMallocDefault);
+  constexpr int NE = hm_workspace_s::G_MAX * hm_workspace_s::N_ACT;
+  e = hipHostMalloc(reinterpret_cast<void**>(&w->h_act_count), NE * sizeof(int), hipHostMallocDefault);
   int n_ev = 0;
+  hipEvent_t* evs = &w->ev_act[0][0];
   if (e == hipSuccess) {
     w->act_ready = true;
-    for (; n_ev < hm_workspace_s::N_ACT; ++n_ev)
-      if (hipEventCreateWithFlags(&w->ev_act[n_ev], hipEventDisableTiming) != hipSuccess) { w->act_ready = false; break; }
+    for (; n_ev < NE; ++n_ev)
+      if (hipEventCreateWithFlags(&evs[n_ev], hipEventDisableTiming) != hipSuccess) { w->act_ready = false; break; }
   } else {
     w->h_act_count = nullptr;
   }
   if (!w->act_ready) {
     hm_set_error("pinned host memory / events for the early-stop poll unavailable");
-    for (int i = 0; i < n_ev; ++i) (void)hipEventDestroy(w->ev_act[i]);
+    for (int i = 0; i < n_ev; ++i) (void)hipEventDestroy(evs[i]);
     if (w->h_act_count) (void)hipHostFree(w->h_act_count);
     (void)hipFree(w->d_blob);
     delete w;
@@ -350,6 +376,22 @@ extern "C" int hm_workspace_create(hm_decoder_s* dec, const hm_limits* lim, hm_w
   *out = w;
   return 0;
 }
+
+namespace {
+// streams + fork / join events of the instance groups, created on first use (a workspace that only ever sees small
+// batches or the functional API never needs them)
+int ensure_group_resources(hm_workspace_s* w) {
+  if (w->n_gres == hm_workspace_s::G_MAX) return 0;
+  HM_CHECK_HIP(hipEventCreateWithFlags(&w->ev_fork, hipEventDisableTiming));
+  for (int g = 0; g < hm_workspace_s::G_MAX; ++g) {
+    HM_CHECK_HIP(hipStreamCreateWithFlags(&w->gstream[g], hipStreamNonBlocking));
+    HM_CHECK_HIP(hipEventCreateWithFlags(&w->ev_join[g], hipEventDisableTiming));
+    HM_CHECK_HIP(hipEventCreateWithFlags(&w->ev_stagger[g], hipEventDisableTiming));
+    w->n_gres = g + 1;
+  }
+  return 0;
+}
+}  // namespace
 
 extern "C" int hm_workspace_profile(hm_workspace_s* w, int enable) {
   if (w == nullptr) { hm_set_error("null workspace"); return -1; }
@@ -377,22 +419,29 @@ extern "C" int hm_workspace_profile_read(hm_workspace_s* w, double* ms_total, lo
 extern "C" int hm_workspace_counters(hm_workspace_s* w, int enable) {
   if (w == nullptr) { hm_set_error("null workspace"); return -1; }
   w->count_on = enable;
-  if (enable) HM_CHECK_HIP(hipMemset(w->d_counters, 0, N_COUNTER * sizeof(unsigned long long)));
+  if (enable) HM_CHECK_HIP(hipMemset(w->d_counters, 0, hm_workspace_s::G_MAX * N_COUNTER * sizeof(unsigned long long)));
   return 0;
 }
 
 extern "C" int hm_workspace_counters_read(hm_workspace_s* w, long long* out5, void* stream) {
   if (w == nullptr || out5 == nullptr) { hm_set_error("null argument"); return -1; }
   HM_CHECK_HIP(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
-  HM_CHECK_HIP(hipMemcpy(out5, w->d_counters, 5 * sizeof(long long), hipMemcpyDeviceToHost));
+  long long all[hm_workspace_s::G_MAX * N_COUNTER];
+  HM_CHECK_HIP(hipMemcpy(all, w->d_counters, sizeof(all), hipMemcpyDeviceToHost));
+  for (int k = 0; k < 5; ++k) {
+    out5[k] = 0;
+    for (int g = 0; g < hm_workspace_s::G_MAX; ++g) out5[k] += all[g * N_COUNTER + k];
+  }
   return 0;
 }
 
 extern "C" int hm_workspace_destroy(hm_workspace_s* w) {
   if (w == nullptr) return 0;
   for (hipEvent_t e : w->ev) (void)hipEventDestroy(e);
-  if (w->act_ready) for (int i = 0; i < hm_workspace_s::N_ACT; ++i) (void)hipEventDestroy(w->ev_act[i]);
+  if (w->act_ready) for (int i = 0; i < hm_workspace_s::G_MAX * hm_workspace_s::N_ACT; ++i) (void)hipEventDestroy((&w->ev_act[0][0])[i]);
   if (w->h_act_count) (void)hipHostFree(w->h_act_count);
+  for (int g = 0; g < w->n_gres; ++g) { (void)hipStreamDestroy(w->gstream[g]); (void)hipEventDestroy(w->ev_join[g]); (void)hipEventDestroy(w->ev_stagger[g]); }
+  if (w->n_gres > 0) (void)hipEventDestroy(w->ev_fork);
   (void)hipFree(w->d_blob);
   if (w->d_maskR) (void)hipFree(w->d_maskR);
   delete w;
@@ -400,6 +449,201 @@ extern "C" int hm_workspace_destroy(hm_workspace_s* w) {
 }
 
 extern "C" size_t hm_workspace_bytes(hm_workspace_s* w) { return w ? w->blob_bytes + w->maskR_bytes : 0; }
+
+namespace {
+
+// One optimisation in flight: the whole batch, or one instance GROUP of it (a view of the workspace and of the caller's
+// batch arrays, on its own stream).
+struct OptRun {
+  hm_workspace_s* ws;        // the workspace, or a view of it (group)
+  hm_workspace_s* owner;     // the workspace the call was made on (profile events, switches)
+  hm_batch bt;
+  const hm_debug* dbg;
+  hipStream_t st;
+  int g;                     // group index: early-stop slots, counters
+  int mode, P;
+  RenderCfg rcfg;
+  RenderBuffers rb;
+  int n_checks, check_every;
+  bool done;
+};
+
+// instances [b0, b0 + nb) of the caller's batch
+hm_batch batch_view(const hm_workspace_s* ws, const hm_batch* bt, int b0, int nb) {
+  hm_batch v = *bt;
+  const size_t F = ws->lim.max_frames, R = ws->lim.max_rays;
+  v.B = nb;
+  v.d_points_w += (size_t)b0 * bt->points_stride * 3;
+  v.d_n_points += b0;
+  if (v.d_T_wc) v.d_T_wc += (size_t)b0 * F * 16;
+  if (v.d_rays) v.d_rays += (size_t)b0 * F * R * 3;
+  if (v.d_depth) v.d_depth += (size_t)b0 * F * R;
+  if (v.d_n_fg) v.d_n_fg += (size_t)b0 * F;
+  if (v.d_n_bg) v.d_n_bg += (size_t)b0 * F;
+  if (v.d_n_frames) v.d_n_frames += b0;
+  if (v.d_cube_radius) v.d_cube_radius += b0;
+  if (v.d_pose_known) v.d_pose_known += b0;
+  v.d_latent += (size_t)b0 * ws->L;
+  v.d_T_ow += (size_t)b0 * 16;
+  v.d_iter_count += b0;
+  v.d_status += b0;
+  return v;
+}
+
+int opt_begin(OptRun& r, const hm_opt_cfg* cfg) {
+  hm_workspace_s* ws = r.ws;
+  const hm_batch* bt = &r.bt;
+  const int B = bt->B;
+  hipStream_t st = r.st;
+  hipLaunchKernelGGL(k_fill_int, dim3((B + 255) / 256), dim3(256), 0, st, ws->active, B, 1);
+  hipLaunchKernelGGL(k_fill_int, dim3((B + 255) / 256), dim3(256), 0, st, bt->d_iter_count, B, 0);
+  hipLaunchKernelGGL(k_fill_int, dim3((B + 255) / 256), dim3(256), 0, st, bt->d_status, B, 0);
+  hipLaunchKernelGGL(k_check_limits, dim3((B + 255) / 256), dim3(256), 0, st, B, r.mode, bt->d_n_points,
+                     bt->points_stride, bt->d_n_frames, bt->d_n_fg, bt->d_n_bg, ws->lim.max_frames, ws->lim.max_rays,
+                     ws->active, bt->d_status);
+  HM_CHECK_HIP(hipGetLastError());
+  r.rcfg = make_render_cfg(ws, cfg);
+  r.rb = ws->rb;
+  if (r.mode == 0) { bind_inputs(r.rb, bt); r.rb.status = bt->d_status; }
+  // Early stop of the LAUNCH loop.  Finished instances are frozen on the device (`active` flags), so results never depend
+  // on this; but a batch whose instances have all converged by iteration 7 of max_iter 50 would still be sent 43 x 13
+  // launches that find nothing to do (~4 us each: 2-3 ms, more than the work itself for a single fruit).  After every
+  // `check_every` iterations the number of active instances goes to pinned host memory behind an event that the host
+  // POLLS LAG iterations later -- it never waits, so the launch pipeline stays full, and stops enqueueing once a count of
+  // zero has arrived.  With all epsilons zero (forced iterations, the benchmark) only every 8th iteration is checked.
+  const bool can_converge = cfg->epsilon_g > 0.f || cfg->epsilon_c > 0.f || cfg->epsilon_t > 0.f || cfg->epsilon_r > 0.f ||
+                            cfg->epsilon_s > 0.f;
+  r.check_every = can_converge ? 1 : 8;
+  r.n_checks = 0;
+  r.done = false;
+  return 0;
+}
+
+// enqueue LM iteration `it` of one run (or find, without waiting, that all its instances have finished); `after_main`:
+// event to record behind the iteration's main decoder launch (staggered start of the instance groups) or nullptr
+int opt_iteration(OptRun& r, const hm_opt_cfg* cfg, int it, hipEvent_t after_main = nullptr) {
+  hm_workspace_s* ws = r.ws;
+  const hm_batch* bt = &r.bt;
+  const hm_debug* dbg = r.dbg;
+  const RenderCfg& rcfg = r.rcfg;
+  const RenderBuffers& rb = r.rb;
+  hipStream_t st = r.st;
+  const int B = bt->B, L = ws->L, mode = r.mode, P = r.P;
+  constexpr int LAG = 2, N_ACT = hm_workspace_s::N_ACT;
+  hipEvent_t* ev_act = r.owner->ev_act[r.g];
+  int* h_act = r.owner->h_act_count + r.g * N_ACT;
+  int rc;
+  if (r.n_checks > LAG && it % r.check_every == 0) {
+    const int slot = (r.n_checks - 1 - LAG) % N_ACT;
+    const hipError_t q = hipEventQuery(ev_act[slot]);
+    (void)hipGetLastError();                      // hipErrorNotReady is an answer, not a failure: do not leave it behind
+    if (q == hipSuccess && h_act[slot] == 0) { r.done = true; return 0; }
+  }
+  rc = launch_latent_bias(ws->dec, bt->d_latent, L, ws->active, B, ws->c0, ws->c4, st);
+  if (rc) return rc;
+  const bool fused = mode == 0 && fused_path(ws);
+  if (mode == 0) {
+    if (fused) rc = launch_render_front(rcfg, rb, bt->d_T_ow, ws->active, B, st);
+    else rc = render_pass(ws, rcfg, rb, bt, P, ws->active, st);
+    if (rc) return rc;
+  }
+  rc = launch_transform_points(bt->d_points_w, bt->points_stride, bt->d_n_points, bt->d_T_ow, ws->active, B,
+                               ws->nS_stride, ws->ptsS, st);
+  if (rc) return rc;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  hm_workspace_s* own = r.owner;
+  if (own->profile_on) {
+    while (own->ev.size() < own->ev_used + 2) {
+      hipEvent_t e;
+      HM_CHECK_HIP(hipEventCreate(&e));
+      own->ev.push_back(e);
+    }
+    ev0 = own->ev[own->ev_used]; ev1 = own->ev[own->ev_used + 1];
+    own->ev_used += 2;
+    HM_CHECK_HIP(hipEventRecord(ev0, st));
+  }
+  if (fused)     // ONE grid: SDF-term forward+backward tiles, then the forward-only tiles of the ray samples
+    rc = launch_decoder_h_main(ws->dec, B, ws->active, ws->c0, ws->c4, ws->ldJ, ws->ptsS, bt->d_n_points, ws->nS_stride,
+                               ws->yS, ws->JS, P, rb.ptsRc, rb.nRq, ws->nR_stride, rb.sdfR, rb.maskR, st);
+  else
+    rc = launch_decoder(ws->dec, B, ws->ptsS, bt->d_n_points, ws->active, ws->nS_stride, ws->c0, ws->c4, ws->yS,
+                        ws->JS, ws->ldJ, P == 0 ? 6 : P, 1, st, 0);
+  if (rc) return rc;
+  if (ev1) HM_CHECK_HIP(hipEventRecord(ev1, st));
+  if (after_main) HM_CHECK_HIP(hipEventRecord(after_main, st));
+  if (fused) {
+    rc = render_back(ws, rcfg, rb, bt, P, ws->active, st);
+    if (rc) return rc;
+  }
+
+  const bool robust = it >= cfg->robust_iter;                             // optimizer.py:145,183
+  RowSegment segs[3];
+  segs[0] = RowSegment{ws->JS, (size_t)ws->nS_stride * ws->ldJ, 0, bt->d_n_points, 0, nullptr, cfg->w_recon,
+                       robust ? cfg->recon_robust_th : 0.f};
+  int n_seg = 1;
+  if (mode == 0) {
+    const size_t stride = (size_t)2 * ws->nray * ws->ldJ;
+    segs[1] = RowSegment{rb.JR, stride, 0, rb.V, 0, nullptr, cfg->w_depth, robust ? cfg->render_robust_th : 0.f};
+    segs[2] = RowSegment{rb.JR, stride, ws->nray, rb.V, 0, nullptr, cfg->w_mask, 0.f};   // mask never robust (:158)
+    n_seg = 3;
+  }
+  rc = launch_normal_eq(segs, n_seg, L, B, ws->active, ws->Hext, st);
+  if (rc) return rc;
+
+  SolveArgs sa;
+  memset(&sa, 0, sizeof(sa));
+  sa.Hext = ws->Hext; sa.Lfac = ws->Lfac; sa.latent = bt->d_latent; sa.T_ow = bt->d_T_ow;
+  sa.pose_known = bt->d_pose_known; sa.V = mode == 0 ? rb.V : nullptr; sa.nflag = mode == 0 ? rb.nflag : nullptr;
+  sa.active = ws->active; sa.iter_count = bt->d_iter_count; sa.status = bt->d_status; sa.cur_scale = nullptr;
+  sa.dbg_A = dbg ? dbg->d_A : nullptr; sa.dbg_b = dbg ? dbg->d_b : nullptr; sa.dbg_delta = dbg ? dbg->d_delta : nullptr;
+  sa.L = L; sa.P = P; sa.ldJ = ws->ldJ; sa.ld_latent = L; sa.iter = it; sa.max_iter = cfg->max_iter;
+  sa.lm_on = cfg->lm_on; sa.lm_eye = cfg->lm_eye; sa.scale_on = cfg->scale_on;
+  sa.w_code = cfg->w_codereg; sa.s_damp = cfg->s_damp; sa.lam0 = cfg->lm_lambda_0;
+  sa.eps_g = cfg->epsilon_g; sa.eps_c = cfg->epsilon_c; sa.eps_t = cfg->epsilon_t; sa.eps_r = cfg->epsilon_r;
+  sa.eps_s = cfg->epsilon_s;
+  sa.force_direct = own->force_direct;
+  if (own->count_on)
+    hipLaunchKernelGGL(k_accumulate_counts, dim3(1), dim3(256), 0, st, rcfg, rb, B, mode, bt->d_n_points, ws->active,
+                       ws->d_counters);
+  if (dbg && dbg->d_counts && mode == 0)
+    hipLaunchKernelGGL(k_collect_counts, dim3((B + 63) / 64), dim3(64), 0, st, rcfg, rb, B, dbg->d_counts);
+  rc = launch_solve_update(sa, B, st);
+  if (rc) return rc;
+  if ((it + 1) % r.check_every == 0) {
+    const int slot = r.n_checks % N_ACT;
+    hipLaunchKernelGGL(k_count_active, dim3(1), dim3(256), 0, st, ws->active, B, ws->d_act_count + slot);
+    HM_CHECK_HIP(hipMemcpyAsync(h_act + slot, ws->d_act_count + slot, sizeof(int), hipMemcpyDeviceToHost, st));
+    HM_CHECK_HIP(hipEventRecord(ev_act[slot], st));
+    ++r.n_checks;
+  }
+  return 0;
+}
+
+// How many instance groups a call runs as.  The tail of an LM iteration -- the render-Jacobian launch (three quarters of
+// a tile round at the benchmark batch), the normal equations, the per-instance solve (one workgroup per instance) and
+// seven small kernels: 0.39 of the 2.04 ms -- leaves most of the 256 CUs idle, and nothing of iteration i + 1 can start
+// before the solve of iteration i.  Instances are independent, so the batch is cut into groups that run the SAME kernel
+// sequence on their own streams, started one main launch apart: one group's tail then shares the chip with the other
+// group's main launch.  Results do not depend on the grouping (a batched result equals the single-instance result bit
+// for bit; tests/test_gpu_round3.py).  Measured at 64 instances x 200 iterations, enqueued from this one host thread:
+// 1 group 159.7, 2 groups 167.6, 3 groups 167.4, 4 groups 146 instances/s (four host threads with a stream each reached
+// 171: scripts/gpu_two_streams.py) -- automatic = 2 groups from 16 instances on.
+int group_count(const hm_workspace_s* ws, int B, const hm_debug* dbg) {
+  if (dbg != nullptr || ws->profile_on) return 1;     // debug capture / HIP-event timing of single launches: one stream
+  int G = ws->groups_override > 0 ? ws->groups_override : (B >= 16 ? 2 : 1);
+  if (G > hm_workspace_s::G_MAX) G = hm_workspace_s::G_MAX;
+  while (G > 1 && B / G < 4) --G;
+  return G;
+}
+
+}  // namespace
+
+extern "C" int hm_workspace_set_groups(hm_workspace_s* w, int groups) {
+  if (w == nullptr) { hm_set_error("null workspace"); return -1; }
+  if (groups < 0 || groups > hm_workspace_s::G_MAX) { hm_set_error("groups must be 0 (automatic) .. %d", hm_workspace_s::G_MAX); return -1; }
+  w->groups_override = groups;
+  return 0;
+}
 
 extern "C" int hm_optimize_batch(hm_workspace_s* ws, const hm_opt_cfg* cfg, const hm_batch* bt, int mode,
                                  const hm_debug* dbg, void* stream) {
@@ -410,117 +654,68 @@ extern "C" int hm_optimize_batch(hm_workspace_s* ws, const hm_opt_cfg* cfg, cons
   if (mode == 0 && (cfg->n_sample_on_ray < 2 || cfg->n_sample_on_ray > ws->lim.max_samples)) {
     hm_set_error("n_sample_on_ray %d outside [2, %d]", cfg->n_sample_on_ray, ws->lim.max_samples); return -1; }
   hipStream_t st = static_cast<hipStream_t>(stream);
-  const int B = bt->B, L = ws->L;
+  const int B = bt->B;
   const int P = mode == 1 ? 0 : (cfg->scale_on ? 7 : 6);
   rc = begin_call(ws, mode == 0);
   if (rc) return rc;
 
-  hipLaunchKernelGGL(k_fill_int, dim3((B + 255) / 256), dim3(256), 0, st, ws->active, B, 1);
-  hipLaunchKernelGGL(k_fill_int, dim3((B + 255) / 256), dim3(256), 0, st, bt->d_iter_count, B, 0);
-  hipLaunchKernelGGL(k_fill_int, dim3((B + 255) / 256), dim3(256), 0, st, bt->d_status, B, 0);
-  hipLaunchKernelGGL(k_check_limits, dim3((B + 255) / 256), dim3(256), 0, st, B, mode, bt->d_n_points,
-                     bt->points_stride, bt->d_n_frames, bt->d_n_fg, bt->d_n_bg, ws->lim.max_frames, ws->lim.max_rays,
-                     ws->active, bt->d_status);
-  HM_CHECK_HIP(hipGetLastError());
-
-  RenderCfg rcfg = make_render_cfg(ws, cfg);
-  RenderBuffers rb = ws->rb;
-  if (mode == 0) { bind_inputs(rb, bt); rb.status = bt->d_status; }
-  const int force_direct = ws->force_direct;
-
-  // Early stop of the LAUNCH loop.  Finished instances are frozen on the device (`active` flags), so results never depend
-  // on this; but a batch whose instances have all converged by iteration 7 of max_iter 50 would still be sent 43 x 13
-  // launches that find nothing to do (~4 us each: 2-3 ms, more than the work itself for a single fruit).  After every
-  // `check_every` iterations the number of active instances goes to pinned host memory behind an event that the host
-  // POLLS LAG iterations later -- it never waits, so the launch pipeline stays full, and stops enqueueing once a count of
-  // zero has arrived.  With all epsilons zero (forced iterations, the benchmark) only every 8th iteration is checked.
-  const bool can_converge = cfg->epsilon_g > 0.f || cfg->epsilon_c > 0.f || cfg->epsilon_t > 0.f || cfg->epsilon_r > 0.f ||
-                            cfg->epsilon_s > 0.f;
-  const int check_every = can_converge ? 1 : 8;
-  constexpr int LAG = 2, N_ACT = hm_workspace_s::N_ACT;
-  int n_checks = 0;
-  for (int it = 0; it < cfg->max_iter; ++it) {
-    if (n_checks > LAG && it % check_every == 0) {
-      const int slot = (n_checks - 1 - LAG) % N_ACT;
-      const hipError_t q = hipEventQuery(ws->ev_act[slot]);
-      (void)hipGetLastError();                      // hipErrorNotReady is an answer, not a failure: do not leave it behind
-      if (q == hipSuccess && ws->h_act_count[slot] == 0) break;
-    }
-    rc = launch_latent_bias(ws->dec, bt->d_latent, L, ws->active, B, ws->c0, ws->c4, st);
+  const int G = group_count(ws, B, dbg);
+  if (G == 1) {
+    OptRun r;
+    r.ws = ws; r.owner = ws; r.bt = *bt; r.dbg = dbg; r.st = st; r.g = 0; r.mode = mode; r.P = P;
+    rc = opt_begin(r, cfg);
     if (rc) return rc;
-    const bool fused = mode == 0 && fused_path(ws);
-    if (mode == 0) {
-      if (fused) rc = launch_render_front(rcfg, rb, bt->d_T_ow, ws->active, B, st);
-      else rc = render_pass(ws, rcfg, rb, bt, P, ws->active, st);
+    for (int it = 0; it < cfg->max_iter && !r.done; ++it) {
+      rc = opt_iteration(r, cfg, it);
       if (rc) return rc;
     }
-    rc = launch_transform_points(bt->d_points_w, bt->points_stride, bt->d_n_points, bt->d_T_ow, ws->active, B,
-                                 ws->nS_stride, ws->ptsS, st);
+    return 0;
+  }
+
+  // groups: fork from the caller's stream, enqueue the iterations of all groups interleaved (so that no group's queue
+  // runs dry while another one's is being filled), join back into the caller's stream
+  rc = ensure_group_resources(ws);
+  if (rc) return rc;
+  hm_workspace_s views[hm_workspace_s::G_MAX];
+  OptRun runs[hm_workspace_s::G_MAX];
+  const int per = (B + G - 1) / G;
+  int n_run = 0;
+  HM_CHECK_HIP(hipEventRecord(ws->ev_fork, st));
+  for (int g = 0; g < G; ++g) {
+    const int b0 = g * per, nb = (B - b0 < per) ? B - b0 : per;
+    if (nb <= 0) break;
+    views[g] = *ws;                                     // shallow copy, then every buffer pointer moved to instance b0
+    Carver c;
+    c.mode = Carver::VIEW; c.b0 = b0; c.g = g;
+    carve(&views[g], c);
+    OptRun& r = runs[n_run++];
+    r.ws = &views[g]; r.owner = ws; r.bt = batch_view(ws, bt, b0, nb); r.dbg = nullptr; r.st = ws->gstream[g]; r.g = g;
+    r.mode = mode; r.P = P;
+    HM_CHECK_HIP(hipStreamWaitEvent(r.st, ws->ev_fork, 0));
+    // STAGGERED START: group g begins when group g - 1 has finished its first main launch.  Started together, the
+    // groups would stay in phase -- all main launches at once, all tails at once -- and nothing would be gained; offset
+    // by a main launch each, one group's tail runs beside the others' main launches, and identical groups keep that phase.
+    if (n_run > 1) HM_CHECK_HIP(hipStreamWaitEvent(r.st, ws->ev_stagger[runs[n_run - 2].g], 0));
+    rc = opt_begin(r, cfg);
     if (rc) return rc;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    if (ws->profile_on) {
-      while (ws->ev.size() < ws->ev_used + 2) {
-        hipEvent_t e;
-        HM_CHECK_HIP(hipEventCreate(&e));
-        ws->ev.push_back(e);
-      }
-      ev0 = ws->ev[ws->ev_used]; ev1 = ws->ev[ws->ev_used + 1];
-      ws->ev_used += 2;
-      HM_CHECK_HIP(hipEventRecord(ev0, st));
-    }
-    if (fused)     // ONE grid: SDF-term forward+backward tiles, then the forward-only tiles of the ray samples
-      rc = launch_decoder_h_main(ws->dec, B, ws->active, ws->c0, ws->c4, ws->ldJ, ws->ptsS, bt->d_n_points, ws->nS_stride,
-                                 ws->yS, ws->JS, P, rb.ptsRc, rb.nRq, ws->nR_stride, rb.sdfR, rb.maskR, st);
-    else
-      rc = launch_decoder(ws->dec, B, ws->ptsS, bt->d_n_points, ws->active, ws->nS_stride, ws->c0, ws->c4, ws->yS,
-                          ws->JS, ws->ldJ, P == 0 ? 6 : P, 1, st, 0);
-    if (rc) return rc;
-    if (ev1) HM_CHECK_HIP(hipEventRecord(ev1, st));
-    if (fused) {
-      rc = render_back(ws, rcfg, rb, bt, P, ws->active, st);
+    if (cfg->max_iter > 0) {
+      rc = opt_iteration(r, cfg, 0, ws->ev_stagger[g]);
       if (rc) return rc;
     }
-
-    const bool robust = it >= cfg->robust_iter;                             // optimizer.py:145,183
-    RowSegment segs[3];
-    segs[0] = RowSegment{ws->JS, (size_t)ws->nS_stride * ws->ldJ, 0, bt->d_n_points, 0, nullptr, cfg->w_recon,
-                         robust ? cfg->recon_robust_th : 0.f};
-    int n_seg = 1;
-    if (mode == 0) {
-      const size_t stride = (size_t)2 * ws->nray * ws->ldJ;
-      segs[1] = RowSegment{rb.JR, stride, 0, rb.V, 0, nullptr, cfg->w_depth, robust ? cfg->render_robust_th : 0.f};
-      segs[2] = RowSegment{rb.JR, stride, ws->nray, rb.V, 0, nullptr, cfg->w_mask, 0.f};   // mask never robust (:158)
-      n_seg = 3;
+  }
+  for (int it = 1; it < cfg->max_iter; ++it) {
+    bool any = false;
+    for (int k = 0; k < n_run; ++k) {
+      if (runs[k].done) continue;
+      rc = opt_iteration(runs[k], cfg, it);
+      if (rc) return rc;
+      any = any || !runs[k].done;
     }
-    rc = launch_normal_eq(segs, n_seg, L, B, ws->active, ws->Hext, st);
-    if (rc) return rc;
-
-    SolveArgs sa;
-    memset(&sa, 0, sizeof(sa));
-    sa.Hext = ws->Hext; sa.Lfac = ws->Lfac; sa.latent = bt->d_latent; sa.T_ow = bt->d_T_ow;
-    sa.pose_known = bt->d_pose_known; sa.V = mode == 0 ? rb.V : nullptr; sa.nflag = mode == 0 ? rb.nflag : nullptr;
-    sa.active = ws->active; sa.iter_count = bt->d_iter_count; sa.status = bt->d_status; sa.cur_scale = nullptr;
-    sa.dbg_A = dbg ? dbg->d_A : nullptr; sa.dbg_b = dbg ? dbg->d_b : nullptr; sa.dbg_delta = dbg ? dbg->d_delta : nullptr;
-    sa.L = L; sa.P = P; sa.ldJ = ws->ldJ; sa.ld_latent = L; sa.iter = it; sa.max_iter = cfg->max_iter;
-    sa.lm_on = cfg->lm_on; sa.lm_eye = cfg->lm_eye; sa.scale_on = cfg->scale_on;
-    sa.w_code = cfg->w_codereg; sa.s_damp = cfg->s_damp; sa.lam0 = cfg->lm_lambda_0;
-    sa.eps_g = cfg->epsilon_g; sa.eps_c = cfg->epsilon_c; sa.eps_t = cfg->epsilon_t; sa.eps_r = cfg->epsilon_r;
-    sa.eps_s = cfg->epsilon_s;
-    sa.force_direct = force_direct;
-    if (ws->count_on)
-      hipLaunchKernelGGL(k_accumulate_counts, dim3(1), dim3(256), 0, st, rcfg, rb, B, mode, bt->d_n_points, ws->active,
-                         ws->d_counters);
-    if (dbg && dbg->d_counts && mode == 0)
-      hipLaunchKernelGGL(k_collect_counts, dim3((B + 63) / 64), dim3(64), 0, st, rcfg, rb, B, dbg->d_counts);
-    rc = launch_solve_update(sa, B, st);
-    if (rc) return rc;
-    if ((it + 1) % check_every == 0) {
-      const int slot = n_checks % N_ACT;
-      hipLaunchKernelGGL(k_count_active, dim3(1), dim3(256), 0, st, ws->active, B, ws->d_act_count + slot);
-      HM_CHECK_HIP(hipMemcpyAsync(ws->h_act_count + slot, ws->d_act_count + slot, sizeof(int), hipMemcpyDeviceToHost, st));
-      HM_CHECK_HIP(hipEventRecord(ws->ev_act[slot], st));
-      ++n_checks;
-    }
+    if (!any) break;
+  }
+  for (int k = 0; k < n_run; ++k) {
+    HM_CHECK_HIP(hipEventRecord(ws->ev_join[runs[k].g], runs[k].st));
+    HM_CHECK_HIP(hipStreamWaitEvent(st, ws->ev_join[runs[k].g], 0));
   }
   return 0;
 }

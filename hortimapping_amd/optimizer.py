@@ -156,6 +156,14 @@ class Workspace:
     def nbytes(self):
         return int(_lib.lib().hm_workspace_bytes(self.handle))
 
+    def set_groups(self, groups: int):
+        """Instance groups per optimisation call (internal streams): 0 = automatic, 1 = one stream, up to 4.  Results do
+        not depend on it (include/hortimapping_amd_debug.h)."""
+        lib = _lib.lib()
+        lib.hm_workspace_set_groups.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        _lib.check(lib.hm_workspace_set_groups(self.handle, int(groups)), "hm_workspace_set_groups")
+        return self
+
     def release(self):
         if getattr(self, "handle", None):
             _lib.lib().hm_workspace_destroy(self.handle)

@@ -1,10 +1,10 @@
 #!/bin/bash
 # pmc_k1h.sh: SQ / TA / TCP / TCC counter passes for the iteration's main K1h launch (one group per pass; --pmc is never
-# combined with other trace domains).  Output: gpurun_out/r03_k1h_pmc_deep.txt
+# combined with other trace domains).  Output: gpurun_out/r04_k1h_pmc_deep.txt
 export TMPDIR=/tmp
 out=gpurun_out; mkdir -p $out
 CMD="python bench.py --steps 1 --warmup 0 --iters 40 --no-cpu-baseline --no-exact $*"
-res=$out/r03_k1h_pmc_deep.txt; : > $res
+res=$out/r04_k1h_pmc_deep.txt; : > $res
 i=0
 for grp in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS" \
            "SQ_INSTS_VMEM_RD SQ_INST_LEVEL_VMEM SQ_VMEM_TA_ADDR_FIFO_FULL SQ_VMEM_TA_CMD_FIFO_FULL SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_VALU_MFMA_COEXEC_CYCLES" \

@@ -94,6 +94,30 @@ def _run(task):
     return out
 
 
+def _run_all(task):
+    """nominal oracle run of candidate k (all candidates, not only the kept ones)"""
+    k, n_iter = task
+    out = os.path.join(SCRATCH + "_all", f"{k:03d}_{n_iter}.npz")
+    if os.path.exists(out):
+        return out
+    import torch
+    torch.set_num_threads(1)
+    from hortimapping_amd import workloads as W
+    from oracle import hm_oracle as O
+    global _OD
+    if _OD is None:
+        _OD = O.fold_decoder(decoder_params())
+    cand = np.load(os.path.join(HERE, "wc_candidates.npz"))
+    d = instance_from(cand, k)
+    rd = {key: [torch.from_numpy(a) for a in v] for key, v in d["render"].items()}
+    z, T, n = O.shape_pose_joint_opt(_OD, W.wc_opt_cfg(max_iter=n_iter), torch.from_numpy(d["latent0"]),
+                                     torch.from_numpy(d["T_ow0"]), rd, torch.from_numpy(d["points_w"]), d["cube_radius"],
+                                     pose_known=False)
+    np.savez(out + ".tmp.npz", latent=z.numpy(), T_ow=T.numpy(), iter_count=n)
+    os.replace(out + ".tmp.npz", out)
+    return out
+
+
 def main():
     import multiprocessing as mp
     stage = sys.argv[1]
@@ -158,8 +182,27 @@ def main():
         np.savez_compressed(os.path.join(HERE, "wc_fullsize_oracle.npz"), **new_orc)
         np.savez_compressed(os.path.join(HERE, "wc_fullsize_reference.npz"), **new_ref)
         print("kept", len(keep), "instances; reference positions", new_ref["inst_ids"].tolist())
+    elif stage == "all_nominal":
+        # the CPU oracle's NOMINAL run on ALL candidates (round 4): sizes the outright-1e-4 claim on the unselected set
+        # (tests/test_gpu_fullsize.py::test_wellconditioned_pass_fraction_over_all_candidates) -> wc_all_oracle.npz
+        cand = np.load(os.path.join(HERE, "wc_candidates.npz"))
+        n = cand["latent0"].shape[0]
+        os.makedirs(SCRATCH + "_all", exist_ok=True)
+        tasks = [(k, 200) for k in range(n)]
+        t0 = time.time()
+        with ctx.Pool(workers) as pool:
+            for j, _ in enumerate(pool.imap_unordered(_run_all, tasks)):
+                print(f"{j + 1}/{n} oracle runs, {time.time() - t0:.0f} s", flush=True)
+        lat = np.zeros((n, L), np.float32)
+        Tow = np.zeros((n, 4, 4), np.float32)
+        for k in range(n):
+            r = np.load(os.path.join(SCRATCH + "_all", f"{k:03d}_200.npz"))
+            assert int(r["iter_count"]) == 200
+            lat[k], Tow[k] = r["latent"], r["T_ow"]
+        np.savez_compressed(os.path.join(HERE, "wc_all_oracle.npz"), free_latent=lat, free_T_ow=Tow, inst_ids=cand["inst_ids"], n_iter=200)
+        print("written wc_all_oracle.npz", flush=True)
     else:
-        raise SystemExit("stage: inputs | records | prune")
+        raise SystemExit("stage: inputs | records | prune | all_nominal")
 
 
 if __name__ == "__main__":

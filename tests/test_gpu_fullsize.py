@@ -479,6 +479,59 @@ def test_wellconditioned_free_pose_parity(precision):
         assert not np.all(dev <= tol), f"{precision} passes the fp32-class gate: the gate has no power"
 
 
+def test_wellconditioned_pass_fraction_over_all_candidates(precision):
+    """Sizes the outright-1e-4 claim honestly (round-3 review): `test_wellconditioned_free_pose_parity` runs on the 23 of
+    128 candidate instances whose own response to one-ulp input perturbations is smallest (a selection on CONDITIONING, made
+    with the HIP f32 path: tests/golden/wc_selection.json).  Here ALL 128 candidates are optimised and compared with the
+    CPU oracle's nominal run (tests/golden/wc_all_oracle.npz, `make_wc_records.py all_nominal`); the fraction that meets
+    1e-4 outright is REPORTED next to the fraction whose own one-ulp response stays inside the tolerance -- on an
+    ill-conditioned candidate no two arithmetics (not even two runs of the reference on inputs one ulp apart) agree to
+    1e-4, so the first fraction cannot exceed the second by much.  Asserted: the selected instances are among the passing
+    ones, and an fp32-class arithmetic passes wherever the instance itself is stable to a third of the tolerance."""
+    import json
+    import os
+    from golden_util import GOLDEN_DIR
+    from hortimapping_amd import metrics as MX, optimizer as HO, workloads as W
+    from hortimapping_amd.decoder import DecoderWeights
+    f_all = os.path.join(GOLDEN_DIR, "wc_all_oracle.npz")
+    if not os.path.exists(f_all):
+        pytest.skip("tests/golden/wc_all_oracle.npz not generated")
+    if precision not in ("f32", "f16x3"):
+        pytest.skip("fp32-class arithmetics only")
+    cand, rec = np.load(os.path.join(GOLDEN_DIR, "wc_candidates.npz")), np.load(f_all)
+    sel = json.load(open(os.path.join(GOLDEN_DIR, "wc_selection.json")))
+    kept_ids = set(np.load(os.path.join(GOLDEN_DIR, "wc_fullsize_inputs.npz"))["inst_ids"].tolist())
+    n = cand["latent0"].shape[0]
+    assert rec["free_latent"].shape[0] == n and np.array_equal(rec["inst_ids"], cand["inst_ids"])
+    params = W.wc_decoder_params(L)
+    sampler = DecoderWeights.from_params(params).set_precision("f32")
+    gt = MX.ground_truth_points_world(sampler, cand["z_true"], cand["T_wo_true"])
+    m_cpu = MX.completion_metrics(sampler, rec["free_latent"], rec["free_T_ow"], gt, cand["T_wo_true"])
+    dec = DecoderWeights.from_params(params).set_precision(precision)
+    res = HO.optimize_batch(dec, W.wc_opt_cfg(max_iter=200), [W.to_instance(d, pose_known=False) for d in W.fixture_dicts(cand)])
+    assert all(r.iter_count == 200 and r.status == 8 for r in res)
+    m_gpu = MX.completion_metrics(sampler, torch.stack([r.latent for r in res]).numpy(), [r.T_ow.numpy() for r in res], gt, cand["T_wo_true"])
+    scale = np.stack([m_cpu[:, 0], np.maximum(m_cpu[:, 1], 1e-3), np.maximum(m_cpu[:, 2], 0.1), np.ones(n)], axis=1)
+    used = (np.abs(m_gpu - m_cpu) / (REL_FLOOR * scale)).max(axis=1)              # fraction of the tolerance used, per candidate
+    own = np.array(sel["score"])                                                   # the candidate's own one-ulp response / tolerance
+    ok = used <= 1.0
+    kept = np.array([int(i) in kept_ids for i in cand["inst_ids"]])
+    lines = [f"# well-conditioned CONFIGURATION, all {n} candidate instances x 200 LM iterations, free Sim(3) pose, GPU {precision} vs the CPU oracle's nominal run",
+             f"# meet 1e-4 outright (all four metrics): {int(ok.sum())} of {n} = {ok.mean():.2f};  of the {int(kept.sum())} selected: {int(ok[kept].sum())}",
+             f"# candidates whose OWN response to 16 one-ulp input perturbations (HIP f32, wc_selection.json) stays inside the tolerance: "
+             f"{int((own <= 1.0).sum())} of {n} = {(own <= 1.0).mean():.2f}; inside a third of it: {int((own <= 1 / 3).sum())}",
+             f"# GPU-vs-oracle tolerance use: median {np.median(used):.2f}, p90 {np.percentile(used, 90):.2f}, max {used.max():.1f};  own response: median {np.median(own):.2f}, p90 {np.percentile(own, 90):.2f}",
+             "# id  own_response/tol  gpu_vs_oracle/tol  selected"]
+    lines += [f"{int(cand['inst_ids'][i]):3d} {own[i]:8.2f} {used[i]:8.2f}  {'*' if kept[i] else ''}" for i in range(n)]
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open(os.path.join("gpurun_out", f"r04_parity_wellconditioned_all_candidates_{precision}.txt"), "w") as f:
+        f.write("\n".join(lines) + "\n")
+    print("\n" + "\n".join(lines[:4]))
+    assert np.all(ok[kept])
+    stable = own <= 1.0 / 3.0
+    assert np.all(ok[stable]), [(int(cand["inst_ids"][i]), float(own[i]), float(used[i])) for i in np.nonzero(stable & ~ok)[0]]
+
+
 @pytest.mark.parametrize("npts", [1024, 2048])
 def test_shape_only_fullsize_state_parity(precision, npts):
     """The shape-only loop (`shape_opt_deepsdf`, bench.py's `c2_sdf` line) at full size -- L = 256, 200 forced iterations,
