@@ -528,7 +528,12 @@ def test_wellconditioned_pass_fraction_over_all_candidates(precision):
         f.write("\n".join(lines) + "\n")
     print("\n" + "\n".join(lines[:4]))
     assert np.all(ok[kept])
-    stable = own <= 1.0 / 3.0
+    # ... and wherever the instance itself is stable to a third of the tolerance -- except the candidates whose CPU-ORACLE runs
+    # spread by more than half the tolerance among themselves (wc_fixture_report.json: candidate 17, a second basin that the
+    # oracle, f32 and f16x3 all see: `make_wc_records.py prune`)
+    rep = json.load(open(os.path.join(GOLDEN_DIR, "wc_fixture_report.json")))
+    oracle_unstable = {i for i, f in zip(rep["inst_ids"], rep["oracle_noise_frac"]) if f > 0.5}
+    stable = (own <= 1.0 / 3.0) & ~np.array([int(i) in oracle_unstable for i in cand["inst_ids"]])
     assert np.all(ok[stable]), [(int(cand["inst_ids"][i]), float(own[i]), float(used[i])) for i in np.nonzero(stable & ~ok)[0]]
 
 
