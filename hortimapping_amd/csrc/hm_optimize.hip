@@ -510,7 +510,9 @@ int opt_begin(OptRun& r, const hm_opt_cfg* cfg) {
   // launches that find nothing to do (~4 us each: 2-3 ms, more than the work itself for a single fruit).  After every
   // `check_every` iterations the number of active instances goes to pinned host memory behind an event that the host
   // POLLS LAG iterations later -- it never waits, so the launch pipeline stays full, and stops enqueueing once a count of
-  // zero has arrived.  With all epsilons zero (forced iterations, the benchmark) only every 8th iteration is checked.
+  // zero has arrived.  With all epsilons zero (forced iterations, the benchmark) only every 8th iteration is checked, and
+  // never waited for; when exits are possible the host additionally stays within LAG + 1 iterations of the device
+  // (opt_iteration), otherwise it would have enqueued everything before the first count arrives.
   const bool can_converge = cfg->epsilon_g > 0.f || cfg->epsilon_c > 0.f || cfg->epsilon_t > 0.f || cfg->epsilon_r > 0.f ||
                             cfg->epsilon_s > 0.f;
   r.check_every = can_converge ? 1 : 8;
@@ -535,8 +537,18 @@ int opt_iteration(OptRun& r, const hm_opt_cfg* cfg, int it, hipEvent_t after_mai
   int rc;
   if (r.n_checks > LAG && it % r.check_every == 0) {
     const int slot = (r.n_checks - 1 - LAG) % N_ACT;
-    const hipError_t q = hipEventQuery(ev_act[slot]);
-    (void)hipGetLastError();                      // hipErrorNotReady is an answer, not a failure: do not leave it behind
+    hipError_t q;
+    if (r.check_every == 1) {
+      // Early exits possible: do not let the host run more than LAG + 1 iterations ahead of the device.  Enqueueing an
+      // iteration costs ~60 us, executing it 2 ms and more, so a host that never waits has sent all max_iter iterations
+      // before the second one has finished and the poll below could never stop anything (wild_pepper.yaml: 35 of 50
+      // iterations of empty launches per batch, and 43 x 13 launches = ~2 ms of a 12 ms single-fruit call).  The queue
+      // stays LAG + 1 iterations deep, so the device never waits for the host.
+      q = hipEventSynchronize(ev_act[slot]);
+    } else {
+      q = hipEventQuery(ev_act[slot]);
+      (void)hipGetLastError();                    // hipErrorNotReady is an answer, not a failure: do not leave it behind
+    }
     if (q == hipSuccess && h_act[slot] == 0) { r.done = true; return 0; }
   }
   rc = launch_latent_bias(ws->dec, bt->d_latent, L, ws->active, B, ws->c0, ws->c4, st);
