@@ -146,10 +146,12 @@ __device__ __forceinline__ void load_b(BSet& b, const f16x8* xh, const f16x8* xl
   b.l0 = xl[k * 2 * TQ + xo]; b.l1 = xl[k * 2 * TQ + xo + 32];
 }
 
-#if defined(HM_ABL_NOMFMA)
-#define HM_MFMA(A, B, C) asm volatile("" : "+v"(C) : "v"(A), "v"(B))
+#ifdef HM_EXPERIMENTAL      // timing ablations of the K step (HM_ABL_*): experimental builds only
+#include "experimental/hm_ablation.inc"
 #else
 #define HM_MFMA(A, B, C) C = __builtin_amdgcn_mfma_f32_32x32x16_f16(A, B, C, 0, 0, 0)
+#define HM_LDA(dst, src) dst = src
+#define HM_LDB(dst, src) dst = src
 #endif
 #define HM_FENCE() __builtin_amdgcn_sched_barrier(0)
 
@@ -165,16 +167,6 @@ __device__ __forceinline__ void step_h(f32x16 (&acc)[2][2], const ASet& a, const
   const f16x8* w1 = wp1 + ka * 128;
   const f16x8* ph = xh + kb * 2 * TQ + xo;
   const f16x8* pl = xl + kb * 2 * TQ + xo;
-#if defined(HM_ABL_NOA)          // timing ablations (scripts/build_variant.sh): wrong results
-#define HM_LDA(dst, src)
-#else
-#define HM_LDA(dst, src) dst = src
-#endif
-#if defined(HM_ABL_NOB)
-#define HM_LDB(dst, src)
-#else
-#define HM_LDB(dst, src) dst = src
-#endif
   if (U0 && U1) {
     const f16x8 a0c = a.h0 * cs;
     const f16x8 a1c = a.h1 * cs;
