@@ -204,10 +204,13 @@ __device__ __forceinline__ void step_h(f32x16 (&acc)[2][2], const ASet& a, const
   }
 }
 
-template <bool U0, bool U1>
+// ALT (experimental builds, tune bit 4): the two waves of a SIMD take turns at `s_setprio 1`, one group of six K-steps
+// (or two, `alt_shift` = 1) each, so that neither runs ahead of the other for a whole K loop (`alt_half` = 0 for the
+// older half of the workgroup, 1 for the younger).
+template <bool U0, bool U1, bool ALT = false>
 __device__ __forceinline__ void gemm_loop_h(f32x16 (&acc)[2][2], const f16x8* __restrict__ wp0,
                                             const f16x8* __restrict__ wp1, int n_k16, const f16x8* xh,
-                                            const f16x8* xl, int lane) {
+                                            const f16x8* xl, int lane, int alt_half = 0, int alt_shift = 0) {
   const int xo = (lane >> 5) * TQ + (lane & 31);
   const int last = n_k16 - 1;
   ASet a0 = {}, a1 = {}, a2 = {};
@@ -223,8 +226,13 @@ __device__ __forceinline__ void gemm_loop_h(f32x16 (&acc)[2][2], const f16x8* __
   // full groups of six run branch-free: with a conditional per step hipcc's wait-count pass merges the "step
   // skipped" paths and emits vmcnt(1) where vmcnt(4+) is right, which cuts the two-step prefetch distance to one
   int ks = 0;
+  int grp6 = 0;
 #define HM_COND(I) true
   for (; ks + 6 <= n_k16; ks += 6) {
+    if (ALT) {
+      if ((((grp6 >> alt_shift) & 1) ^ alt_half) != 0) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+      ++grp6;
+    }
     HM_STEP(a0, b0, a2, b1, 0)
     HM_STEP(a1, b1, a0, b0, 1)
     HM_STEP(a2, b0, a1, b1, 2)
@@ -243,6 +251,7 @@ __device__ __forceinline__ void gemm_loop_h(f32x16 (&acc)[2][2], const f16x8* __
   }
 #undef HM_COND
 #undef HM_STEP
+  if (ALT) __builtin_amdgcn_s_setprio(0);
 }
 
 
@@ -538,6 +547,7 @@ __global__ __launch_bounds__(512, 2) void k_decoder_h(const DecodeArgsH a) {
         if (u0 && u1) {
 #ifdef HM_EXPERIMENTAL
           if (!BW1 && (a.tune & 8)) gemm_loop_h4<true, true>(acc, wp0, wp1, sh.n_k16, xh, xl, lane);
+          else if (!BW1 && (a.tune & 16)) gemm_loop_h<true, true, true>(acc, wp0, wp1, sh.n_k16, xh, xl, lane, w >> 2, (a.tune >> 5) & 1);
           else
 #endif
           gemm_loop_h<true, true>(acc, wp0, wp1, sh.n_k16, xh, xl, lane);

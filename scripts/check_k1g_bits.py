@@ -10,7 +10,7 @@ from hortimapping_amd.decoder import DecoderWeights
 
 lib = _lib.lib()
 assert hasattr(lib, "hm_debug_k1h_variant"), "not an experimental build (HORTIHIP_LIB)"
-CASES = [(0, 0), (1, 0), (1, 1), (1, 2), (2, 0), (0, 8)]          # (variant, tune)
+CASES = [(0, 0), (1, 0), (1, 1), (1, 2), (2, 0), (0, 8), (0, 0x10), (0, 0x30)]          # (variant, tune)
 for L in (32, 64, 96, 128, 160, 192, 224, 256):
     dec = DecoderWeights.from_params(S.make_synthetic_decoder(L, seed=7, r0=0.04, aniso=(1.0, 0.75, 1.3), bias_sigma=0.02))
     dec.set_precision("f16x3")
