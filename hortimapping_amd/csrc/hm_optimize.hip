@@ -685,7 +685,8 @@ extern "C" int hm_optimize_batch(hm_workspace_s* ws, const hm_opt_cfg* cfg, cons
   }
 
   // groups: fork from the caller's stream, enqueue the iterations of all groups interleaved (so that no group's queue
-  // runs dry while another one's is being filled), join back into the caller's stream
+  // runs dry while another one's is being filled), join back into the caller's stream -- also when an enqueue fails half
+  // way: whatever was sent to the internal streams is ordered before the caller's next operation
   rc = ensure_group_resources(ws);
   if (rc) return rc;
   hm_workspace_s views[hm_workspace_s::G_MAX];
@@ -693,43 +694,48 @@ extern "C" int hm_optimize_batch(hm_workspace_s* ws, const hm_opt_cfg* cfg, cons
   const int per = (B + G - 1) / G;
   int n_run = 0;
   HM_CHECK_HIP(hipEventRecord(ws->ev_fork, st));
-  for (int g = 0; g < G; ++g) {
-    const int b0 = g * per, nb = (B - b0 < per) ? B - b0 : per;
-    if (nb <= 0) break;
-    views[g] = *ws;                                     // shallow copy, then every buffer pointer moved to instance b0
-    Carver c;
-    c.mode = Carver::VIEW; c.b0 = b0; c.g = g;
-    carve(&views[g], c);
-    OptRun& r = runs[n_run++];
-    r.ws = &views[g]; r.owner = ws; r.bt = batch_view(ws, bt, b0, nb); r.dbg = nullptr; r.st = ws->gstream[g]; r.g = g;
-    r.mode = mode; r.P = P;
-    HM_CHECK_HIP(hipStreamWaitEvent(r.st, ws->ev_fork, 0));
-    // STAGGERED START: group g begins when group g - 1 has finished its first main launch.  Started together, the
-    // groups would stay in phase -- all main launches at once, all tails at once -- and nothing would be gained; offset
-    // by a main launch each, one group's tail runs beside the others' main launches, and identical groups keep that phase.
-    if (n_run > 1) HM_CHECK_HIP(hipStreamWaitEvent(r.st, ws->ev_stagger[runs[n_run - 2].g], 0));
-    rc = opt_begin(r, cfg);
-    if (rc) return rc;
-    if (cfg->max_iter > 0) {
-      rc = opt_iteration(r, cfg, 0, ws->ev_stagger[g]);
-      if (rc) return rc;
+  auto enqueue_all = [&]() -> int {
+    for (int g = 0; g < G; ++g) {
+      const int b0 = g * per, nb = (B - b0 < per) ? B - b0 : per;
+      if (nb <= 0) break;
+      views[g] = *ws;                                   // shallow copy, then every buffer pointer moved to instance b0
+      Carver c;
+      c.mode = Carver::VIEW; c.b0 = b0; c.g = g;
+      carve(&views[g], c);
+      OptRun& r = runs[n_run++];
+      r.ws = &views[g]; r.owner = ws; r.bt = batch_view(ws, bt, b0, nb); r.dbg = nullptr; r.st = ws->gstream[g]; r.g = g;
+      r.mode = mode; r.P = P;
+      HM_CHECK_HIP(hipStreamWaitEvent(r.st, ws->ev_fork, 0));
+      // STAGGERED START: group g begins when group g - 1 has finished its first main launch.  Started together, the
+      // groups would stay in phase -- all main launches at once, all tails at once -- and nothing would be gained (measured:
+      // slower than one stream); offset by a main launch each, one group's tail runs beside the other's main launch, and
+      // identical groups keep that phase.
+      if (n_run > 1) HM_CHECK_HIP(hipStreamWaitEvent(r.st, ws->ev_stagger[runs[n_run - 2].g], 0));
+      int e = opt_begin(r, cfg);
+      if (e) return e;
+      if (cfg->max_iter > 0) {
+        e = opt_iteration(r, cfg, 0, ws->ev_stagger[g]);
+        if (e) return e;
+      }
     }
-  }
-  for (int it = 1; it < cfg->max_iter; ++it) {
-    bool any = false;
-    for (int k = 0; k < n_run; ++k) {
-      if (runs[k].done) continue;
-      rc = opt_iteration(runs[k], cfg, it);
-      if (rc) return rc;
-      any = any || !runs[k].done;
+    for (int it = 1; it < cfg->max_iter; ++it) {
+      bool any = false;
+      for (int k = 0; k < n_run; ++k) {
+        if (runs[k].done) continue;
+        const int e = opt_iteration(runs[k], cfg, it);
+        if (e) return e;
+        any = any || !runs[k].done;
+      }
+      if (!any) break;
     }
-    if (!any) break;
-  }
+    return 0;
+  };
+  rc = enqueue_all();
   for (int k = 0; k < n_run; ++k) {
-    HM_CHECK_HIP(hipEventRecord(ws->ev_join[runs[k].g], runs[k].st));
-    HM_CHECK_HIP(hipStreamWaitEvent(st, ws->ev_join[runs[k].g], 0));
+    if (hipEventRecord(ws->ev_join[runs[k].g], runs[k].st) == hipSuccess)
+      (void)hipStreamWaitEvent(st, ws->ev_join[runs[k].g], 0);
   }
-  return 0;
+  return rc;
 }
 
 extern "C" int hm_render_residuals(hm_workspace_s* ws, const hm_opt_cfg* cfg, const hm_batch* bt,
