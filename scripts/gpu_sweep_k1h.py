@@ -16,6 +16,7 @@ lat = (0.07 * torch.randn(B, L)).float().cuda()
 pts4 = torch.zeros(B, n, 4); pts4[..., :3] = 0.04 * torch.randn(B, n, 3); pts4 = pts4.cuda()
 nq = torch.full((B,), n, dtype=torch.int32).cuda()
 lib = _lib.lib()
+EXP = hasattr(lib, 'hm_debug_k1h_variant')          # product library: only the product kernel can be timed
 
 def timed(mode, reps=30):
     for _ in range(3): ops.decode_batch(dec, lat, pts4, nq, mode=mode, pose_dim=7)
@@ -31,9 +32,10 @@ for rnd in range(2):
     for var in (0, 1, 2):
         for tune in tunes:
             if (var != 1 and (tune & 3)) or (var != 0 and (tune & 0x38)): continue
-            lib.hm_debug_k1h_variant(var); lib.hm_debug_k1h_tune(tune)
+            if not EXP and (var or tune): continue
+            if EXP: lib.hm_debug_k1h_variant(var); lib.hm_debug_k1h_tune(tune)
             y, J = ops.decode_batch(dec, lat, pts4, nq, mode=1, pose_dim=7)
             if ref is None: ref = (y.clone(), J.clone())
             same = bool(torch.equal(y, ref[0]) and torch.equal(J, ref[1]))
             print(f"L={L} variant {var} tune {tune:#04x}: fwd+bwd {timed(1):.4f} ms, fwd {timed(0):.4f} ms  bits_equal={same}", flush=True)
-lib.hm_debug_k1h_variant(0); lib.hm_debug_k1h_tune(0)
+if EXP: lib.hm_debug_k1h_variant(0); lib.hm_debug_k1h_tune(0)
