@@ -637,12 +637,16 @@ int opt_iteration(OptRun& r, const hm_opt_cfg* cfg, int it, hipEvent_t after_mai
 // before the solve of iteration i.  Instances are independent, so the batch is cut into groups that run the SAME kernel
 // sequence on their own streams, started one main launch apart: one group's tail then shares the chip with the other
 // group's main launch.  Results do not depend on the grouping (a batched result equals the single-instance result bit
-// for bit; tests/test_gpu_round3.py).  Measured at 64 instances x 200 iterations, enqueued from this one host thread:
-// 1 group 159.7, 2 groups 167.6, 3 groups 167.4, 4 groups 146 instances/s (four host threads with a stream each reached
-// 171: scripts/gpu_two_streams.py) -- automatic = 2 groups from 16 instances on.
+// for bit; tests/test_gpu_round3.py).  Measured at 64 instances x 200 iterations, enqueued from this one host thread
+// (scripts/run_groups_check.sh, four runs each): 1 group 159.7, 2 groups 166.3-169.1, 3 groups 167.4-171.1, 4 groups
+// 146-147 instances/s -- four group streams plus the caller's exceed the runtime's four hardware queues per process, two
+// streams then share a queue and serialise (158 with GPU_MAX_HW_QUEUES=8).  Whether the groups start together or one
+// main launch apart matters little once they are three or fewer (the staggered start is kept: it is what the picture
+// above describes and never measured slower).  Same-box A/B on a slower box: joint 153 / 160 / 161, shape-only 122.2 / 123.6 /
+// 122.7 instances/s for 1 / 2 / 3 groups.  Automatic: 2 groups from 16 instances on.
 int group_count(const hm_workspace_s* ws, int B, const hm_debug* dbg) {
   if (dbg != nullptr || ws->profile_on) return 1;     // debug capture / HIP-event timing of single launches: one stream
-  int G = ws->groups_override > 0 ? ws->groups_override : (B >= 16 ? 2 : 1);
+  int G = (ws->groups_override & 15) > 0 ? (ws->groups_override & 15) : (B >= 16 ? 2 : 1);
   if (G > hm_workspace_s::G_MAX) G = hm_workspace_s::G_MAX;
   while (G > 1 && B / G < 4) --G;
   return G;
@@ -652,7 +656,8 @@ int group_count(const hm_workspace_s* ws, int B, const hm_debug* dbg) {
 
 extern "C" int hm_workspace_set_groups(hm_workspace_s* w, int groups) {
   if (w == nullptr) { hm_set_error("null workspace"); return -1; }
-  if (groups < 0 || groups > hm_workspace_s::G_MAX) { hm_set_error("groups must be 0 (automatic) .. %d", hm_workspace_s::G_MAX); return -1; }
+  if (groups < 0 || (groups & 15) > hm_workspace_s::G_MAX || (groups >> 4) > 2) {     // bits 4-5: stagger experiment (0 default)
+    hm_set_error("groups must be 0 (automatic) .. %d", hm_workspace_s::G_MAX); return -1; }
   w->groups_override = groups;
   return 0;
 }
@@ -710,12 +715,14 @@ extern "C" int hm_optimize_batch(hm_workspace_s* ws, const hm_opt_cfg* cfg, cons
       // groups would stay in phase -- all main launches at once, all tails at once -- and nothing would be gained (measured:
       // slower than one stream); offset by a main launch each, one group's tail runs beside the other's main launch, and
       // identical groups keep that phase.
-      if (n_run > 1) HM_CHECK_HIP(hipStreamWaitEvent(r.st, ws->ev_stagger[runs[n_run - 2].g], 0));
+      const int stagger_mode = ws->groups_override >> 4;      // experiments: 1 = start together, 2 = one whole iteration apart
+      if (n_run > 1 && stagger_mode != 1) HM_CHECK_HIP(hipStreamWaitEvent(r.st, ws->ev_stagger[runs[n_run - 2].g], 0));
       int e = opt_begin(r, cfg);
       if (e) return e;
       if (cfg->max_iter > 0) {
-        e = opt_iteration(r, cfg, 0, ws->ev_stagger[g]);
+        e = opt_iteration(r, cfg, 0, stagger_mode == 2 ? nullptr : ws->ev_stagger[g]);
         if (e) return e;
+        if (stagger_mode == 2) HM_CHECK_HIP(hipEventRecord(ws->ev_stagger[g], r.st));
       }
     }
     for (int it = 1; it < cfg->max_iter; ++it) {
