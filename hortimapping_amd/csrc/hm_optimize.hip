@@ -51,8 +51,10 @@ struct hm_workspace_s {
   // instance groups: internal streams + fork / join events; 0 = automatic group count
   hipStream_t gstream[G_MAX];
   hipEvent_t ev_fork, ev_join[G_MAX], ev_stagger[G_MAX];
-  int n_gres;                     // group resources created so far (all or none)
+  int n_gres;                     // group streams (+ their join / stagger events) created so far
+  bool have_fork;                 // ev_fork exists
   int groups_override;
+  int host_pacing;                // 1: stay <= LAG + 1 iterations ahead of the device when early exits are possible
   // test / A-B switches, scoped to THIS workspace: the override set by hm_workspace_set_debug (-1 = follow the process
   // default of hm_debug_split_render / hm_debug_force_direct_solve) and the value snapshotted when an entry point is
   // called -- one call never sees a switch change under it (a mask-less forward paired with a mask-reading backward)
@@ -340,7 +342,7 @@ extern "C" int hm_workspace_create(hm_decoder_s* dec, const hm_limits* lim, hm_w
   w->nR_stride = round_up(w->nray * w->lim.max_samples, TQ);
   const int cap = lim->max_grad_samples > 0 ? lim->max_grad_samples : w->nray * w->lim.max_samples;
   w->nG_stride = round_up(cap, TQ);
-  w->n_gres = 0; w->groups_override = 0;
+  w->n_gres = 0; w->have_fork = false; w->groups_override = 0; w->host_pacing = 1;
   Carver size_pass;
   carve(w, size_pass);
   w->blob_bytes = size_pass.off + 256;
@@ -380,13 +382,28 @@ extern "C" int hm_workspace_create(hm_decoder_s* dec, const hm_limits* lim, hm_w
 namespace {
 // streams + fork / join events of the instance groups, created on first use (a workspace that only ever sees small
 // batches or the functional API never needs them)
-int ensure_group_resources(hm_workspace_s* w) {
-  if (w->n_gres == hm_workspace_s::G_MAX) return 0;
-  HM_CHECK_HIP(hipEventCreateWithFlags(&w->ev_fork, hipEventDisableTiming));
-  for (int g = 0; g < hm_workspace_s::G_MAX; ++g) {
-    HM_CHECK_HIP(hipStreamCreateWithFlags(&w->gstream[g], hipStreamNonBlocking));
-    HM_CHECK_HIP(hipEventCreateWithFlags(&w->ev_join[g], hipEventDisableTiming));
-    HM_CHECK_HIP(hipEventCreateWithFlags(&w->ev_stagger[g], hipEventDisableTiming));
+// Creates what is missing for G groups and nothing more; a failure half way leaves every handle created so far
+// registered (n_gres / have_fork), so that a later call resumes from there and hm_workspace_destroy frees them all.
+int ensure_group_resources(hm_workspace_s* w, int G) {
+  if (!w->have_fork) {
+    HM_CHECK_HIP(hipEventCreateWithFlags(&w->ev_fork, hipEventDisableTiming));
+    w->have_fork = true;
+  }
+  while (w->n_gres < G) {
+    const int g = w->n_gres;
+    hipStream_t s = nullptr;
+    hipEvent_t ej = nullptr, es = nullptr;
+    hipError_t e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ej, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&es, hipEventDisableTiming);
+    if (e != hipSuccess) {
+      if (es) (void)hipEventDestroy(es);
+      if (ej) (void)hipEventDestroy(ej);
+      if (s) (void)hipStreamDestroy(s);
+      hm_set_error("creating the stream / events of instance group %d failed: %s", g, hipGetErrorString(e));
+      return -2;
+    }
+    w->gstream[g] = s; w->ev_join[g] = ej; w->ev_stagger[g] = es;
     w->n_gres = g + 1;
   }
   return 0;
@@ -441,7 +458,7 @@ extern "C" int hm_workspace_destroy(hm_workspace_s* w) {
   if (w->act_ready) for (int i = 0; i < hm_workspace_s::G_MAX * hm_workspace_s::N_ACT; ++i) (void)hipEventDestroy((&w->ev_act[0][0])[i]);
   if (w->h_act_count) (void)hipHostFree(w->h_act_count);
   for (int g = 0; g < w->n_gres; ++g) { (void)hipStreamDestroy(w->gstream[g]); (void)hipEventDestroy(w->ev_join[g]); (void)hipEventDestroy(w->ev_stagger[g]); }
-  if (w->n_gres > 0) (void)hipEventDestroy(w->ev_fork);
+  if (w->have_fork) (void)hipEventDestroy(w->ev_fork);
   (void)hipFree(w->d_blob);
   if (w->d_maskR) (void)hipFree(w->d_maskR);
   delete w;
@@ -538,7 +555,7 @@ int opt_iteration(OptRun& r, const hm_opt_cfg* cfg, int it, hipEvent_t after_mai
   if (r.n_checks > LAG && it % r.check_every == 0) {
     const int slot = (r.n_checks - 1 - LAG) % N_ACT;
     hipError_t q;
-    if (r.check_every == 1) {
+    if (r.check_every == 1 && r.owner->host_pacing) {
       // Early exits possible: do not let the host run more than LAG + 1 iterations ahead of the device.  Enqueueing an
       // iteration costs ~60 us, executing it 2 ms and more, so a host that never waits has sent all max_iter iterations
       // before the second one has finished and the poll below could never stop anything (wild_pepper.yaml: 35 of 50
@@ -654,6 +671,12 @@ int group_count(const hm_workspace_s* ws, int B, const hm_debug* dbg) {
 
 }  // namespace
 
+extern "C" int hm_workspace_set_host_pacing(hm_workspace_s* w, int on) {
+  if (w == nullptr) { hm_set_error("null workspace"); return -1; }
+  w->host_pacing = on ? 1 : 0;
+  return 0;
+}
+
 extern "C" int hm_workspace_set_groups(hm_workspace_s* w, int groups) {
   if (w == nullptr) { hm_set_error("null workspace"); return -1; }
   if (groups < 0 || (groups & 15) > hm_workspace_s::G_MAX || (groups >> 4) > 2) {     // bits 4-5: stagger experiment (0 default)
@@ -692,7 +715,7 @@ extern "C" int hm_optimize_batch(hm_workspace_s* ws, const hm_opt_cfg* cfg, cons
   // groups: fork from the caller's stream, enqueue the iterations of all groups interleaved (so that no group's queue
   // runs dry while another one's is being filled), join back into the caller's stream -- also when an enqueue fails half
   // way: whatever was sent to the internal streams is ordered before the caller's next operation
-  rc = ensure_group_resources(ws);
+  rc = ensure_group_resources(ws, G);
   if (rc) return rc;
   hm_workspace_s views[hm_workspace_s::G_MAX];
   OptRun runs[hm_workspace_s::G_MAX];

@@ -85,6 +85,24 @@ class DecoderWeights:
         v = _lib.lib().hm_decoder_get_precision(self.handle)
         return {v_: k for k, v_ in self.PRECISIONS.items()}[v]
 
+    def f32_twin(self) -> "DecoderWeights":
+        """A second handle on the same weights fixed at exact fp32 (created on first use, ~30 MB of HBM).  The exact-f32
+        fallbacks (`optimize_batch(retry_f32=True)`, `MeshExtractor.decode_grids`) run on it instead of switching THIS
+        handle's precision, which is a host field read at enqueue time: flipping it would silently change the arithmetic
+        of any other thread using the decoder in that window."""
+        if self.precision == "f32":
+            return self
+        tw = getattr(self, "_f32_twin", None)
+        if tw is None:
+            env = os.environ.pop("HM_PRECISION", None)          # the twin is f32 whatever the process default says
+            try:
+                tw = DecoderWeights(self.Ws, self.bs, self.latent_dim)
+            finally:
+                if env is not None:
+                    os.environ["HM_PRECISION"] = env
+            self._f32_twin = tw
+        return tw
+
     @classmethod
     def from_params(cls, params):
         """`params`: dict of lin{l}.weight_v/weight_g/bias (+ lin8.weight) arrays plus 'latent_dim'."""

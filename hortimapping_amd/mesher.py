@@ -142,6 +142,16 @@ class MeshExtractor(object):
         pts = self._pts4[None].expand(B, -1, -1).contiguous()
         nq = torch.full((B,), n3, dtype=torch.int32, device="cuda")
         y, _ = ops.decode_batch(self.decoder, lat, pts, nq, mode=0)
+        if self.decoder.precision != "f32":
+            # The fp16-operand arithmetics poison a 64-query tile whose activations leave the fp16 range (NaN sdf, never
+            # silent garbage).  The optimiser retries such instances in exact fp32; the grid decode does the same here, per
+            # instance, so that no NaN reaches marching cubes / the written .ply.
+            bad = (~torch.isfinite(y[:, :n3]).all(dim=1)).nonzero().flatten()
+            if bad.numel():
+                y32, _ = ops.decode_batch(self.decoder.f32_twin(), lat[bad].contiguous(), pts[:bad.numel()].contiguous(),
+                                          nq[:bad.numel()].contiguous(), mode=0)
+                y[bad] = y32
+                self.n_f32_redecoded = getattr(self, "n_f32_redecoded", 0) + int(bad.numel())
         n = self.voxels_dim
         return y[:, :n3].reshape(B, n, n, n)
 

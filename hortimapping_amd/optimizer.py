@@ -156,9 +156,17 @@ class Workspace:
     def nbytes(self):
         return int(_lib.lib().hm_workspace_bytes(self.handle))
 
+    def set_host_pacing(self, on: bool):
+        """False: `hm_optimize_batch` never waits for the device (needed under stream capture; a finished batch is then
+        still sent all max_iter iterations of empty launches).  True (default): see include/hortimapping_amd.h."""
+        lib = _lib.lib()
+        lib.hm_workspace_set_host_pacing.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        _lib.check(lib.hm_workspace_set_host_pacing(self.handle, 1 if on else 0), "hm_workspace_set_host_pacing")
+        return self
+
     def set_groups(self, groups: int):
         """Instance groups per optimisation call (internal streams): 0 = automatic, 1 = one stream, up to 4.  Results do
-        not depend on it (include/hortimapping_amd_debug.h)."""
+        not depend on it (include/hortimapping_amd.h)."""
         lib = _lib.lib()
         lib.hm_workspace_set_groups.argtypes = [ctypes.c_void_p, ctypes.c_int]
         _lib.check(lib.hm_workspace_set_groups(self.handle, int(groups)), "hm_workspace_set_groups")
@@ -292,7 +300,10 @@ def _stream():
 
 
 def run_packed(ws: Workspace, cfg: HmOptCfg, pb: PackedBatch, mode: int, debug: Optional[dict] = None):
-    """Enqueue the whole optimisation of a packed batch (asynchronous w.r.t. the host)."""
+    """Enqueue the whole optimisation of a packed batch on the current stream.  With all epsilons zero this is a pure
+    enqueue; when early exits are possible (any epsilon > 0: every shipped YAML) the C call paces the host to at most three
+    iterations ahead of the device and returns when all but the last iterations have run (include/hortimapping_amd.h,
+    hm_optimize_batch; `Workspace.set_host_pacing(False)` restores the pure enqueue)."""
     lib = _lib.lib()
     _declare_opt(lib)
     bs = pb.as_struct()
@@ -331,21 +342,22 @@ def optimize_batch(dec: DecoderWeights, opt: dict, instances: Sequence[Instance]
     call would dominate its latency.
     `retry_f32`: the fp16-operand arithmetics (f16x3, f16x3f_f16b, f16) cannot represent hidden activations beyond 65504;
     a tile that gets there is poisoned and its instance stops with HM_STATUS_SOLVE_FAILED, its state untouched, where the
-    reference (fp32) simply carries on.  With `retry_f32` every such instance is optimised again from its INITIAL state
-    in exact fp32 -- batched results equal single-instance results bit for bit, so the outcome is the pure-f32 run's --
-    and flagged `retried_f32`; the drop-in `Optimizer` does this, which is what lets it default to f16x3."""
+    reference (fp32) simply carries on.  With `retry_f32` every instance that ends with HM_STATUS_SOLVE_FAILED -- the
+    range guard, or any other non-finite / non-SPD system: the status bit does not tell them apart, and exact fp32 is
+    the reference's arithmetic for both -- is optimised again from its INITIAL state in exact fp32 on the decoder's
+    `f32_twin()` (a second handle: the caller's decoder keeps its precision throughout, so concurrent users of it are not
+    affected).  Batched results equal single-instance results bit for bit, so the outcome is the pure-f32 run's; it is
+    flagged `retried_f32` (= "re-run in f32 after a failed solve", whatever the cause).  The drop-in `Optimizer` does
+    this, which is what lets it default to f16x3."""
     if len(instances) == 0:
         return []
     if retry_f32 and dec.precision != "f32":
         first = optimize_batch(dec, opt, instances, shape_only, workspace, device, debug, cache, retry_f32=False)
         bad = [i for i, r in enumerate(first) if r.status & STATUS_SOLVE_FAILED]
         if bad:
-            prec = dec.precision
-            dec.set_precision("f32")
-            try:         # the initial state: `first` left failed instances untouched, but take the caller's tensors anyway
-                again = optimize_batch(dec, opt, [instances[i] for i in bad], shape_only, None, device, None, cache, retry_f32=False)
-            finally:
-                dec.set_precision(prec)
+            # the initial state: `first` left failed instances untouched, but take the caller's tensors anyway
+            again = optimize_batch(dec.f32_twin(), opt, [instances[i] for i in bad], shape_only, None, device, None,
+                                   cache.setdefault("f32_retry", {}) if cache is not None else None, retry_f32=False)
             for i, r in zip(bad, again):
                 r.retried_f32 = True
                 first[i] = r

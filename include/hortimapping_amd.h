@@ -9,7 +9,9 @@
  * Each entry point below names the reference interface it replaces.  Conventions:
  *   - every function returns 0 on success, < 0 on error (never throws); hm_last_error() describes the failure;
  *   - all `d_*` pointers are device (HBM) pointers owned by the caller; the library never frees caller memory;
- *   - work is enqueued on the caller's hipStream_t (passed as void*); nothing synchronises the host unless stated;
+ *   - work is enqueued on the caller's hipStream_t (passed as void*); nothing synchronises the host unless stated
+ *     (stated exceptions: hm_optimize_batch's host pacing when early exits are possible -- see there and
+ *     hm_workspace_set_host_pacing --, hm_workspace_counters_read, the *_create functions);
  *   - matrices are row-major fp32; index arrays are int32.
  */
 #ifndef HORTIMAPPING_AMD_H
@@ -170,10 +172,36 @@ int hm_workspace_counters(hm_workspace_t ws, int enable);
 int hm_workspace_counters_read(hm_workspace_t ws, long long* out5, void* stream);
 
 /* Replaces Optimizer.shape_pose_joint_opt (mode 0; optimizer.py:28-302) and Optimizer.shape_opt_deepsdf (mode 1;
- * optimizer.py:306-429) for a whole batch.  Enqueues cfg->max_iter iterations on `stream` with no host sync;
- * instances that converge / become invalid are frozen bit-exactly by device-side flags. */
+ * optimizer.py:306-429) for a whole batch.  Instances that converge / become invalid are frozen bit-exactly by
+ * device-side flags; results never depend on anything below.
+ *
+ * Streams.  The work is ordered after everything already on `stream` and before everything the caller enqueues on it
+ * afterwards.  A batch of >= 16 instances is cut into instance groups (hm_workspace_set_groups) that run on INTERNAL
+ * non-blocking streams of the workspace, forked from and joined back into `stream` by events; the caller's stream sees
+ * one fork and one join.  A workspace must not be used by two calls at the same time.
+ *
+ * Host behaviour -- this call is NOT always a pure enqueue:
+ *   - every epsilon_* == 0 (forced iterations): all cfg->max_iter iterations are enqueued and the call returns without
+ *     waiting for the device (the early-stop poll is a hipEventQuery, never a wait);
+ *   - any epsilon_* > 0 (every shipped YAML): early exits are possible, and with host pacing on (the default) the host
+ *     stays at most 3 iterations ahead of the device: from iteration 3 on, each iteration first WAITS
+ *     (hipEventSynchronize) for the active-instance count of the iteration three back -- hence also for everything the
+ *     caller had queued on `stream` before the call -- and stops enqueueing once that count is zero.  The call then
+ *     returns after all but the last <= 3 iterations have EXECUTED.  Why: enqueueing costs ~60 us per iteration, running
+ *     one 2 ms and more; an unpaced host has sent all max_iter iterations before the second has finished and the poll
+ *     can stop nothing (wild_pepper.yaml: 35 of 50 iterations were empty launches).  Consequences: no host/device overlap
+ *     across consecutive calls beyond those last iterations, and the call is ILLEGAL under stream capture
+ *     (hipStreamBeginCapture) -- capture with hm_workspace_set_host_pacing(ws, 0).
+ * hm_workspace_set_host_pacing(ws, 0) restores the pure enqueue for every cfg: the poll becomes a hipEventQuery, all
+ * iterations a finished batch no longer needs are still launched (and find nothing to do: ~50 us each). */
 int hm_optimize_batch(hm_workspace_t ws, const hm_opt_cfg* cfg, const hm_batch* batch, int mode,
                       const hm_debug* dbg, void* stream);
+/* 1 (default): see above; 0: hm_optimize_batch never waits for the device. */
+int hm_workspace_set_host_pacing(hm_workspace_t ws, int on);
+/* Instance groups of hm_optimize_batch (each group runs the kernel sequence on its own internal stream, so that one
+ * group's under-filled iteration tail shares the chip with another group's main launch; results do not depend on it):
+ * 0 = automatic (2 groups from 16 instances on; the default), 1 = everything on the caller's stream, up to 4. */
+int hm_workspace_set_groups(hm_workspace_t ws, int groups);
 
 /* Replaces one call of compute_render_loss per frame (wild_completion/loss.py:8-217) for a batch: runs the render
  * front end + Jacobian pass for the current (latent, T_ow) and leaves, per instance, V[b] depth rows followed (at row

@@ -19,10 +19,7 @@ extern "C" {
  * of the fused grid + backward-only pass from saved ReLU masks (same bits either way); force_direct_solve: 1 = every solve
  * takes the blocked-Cholesky fallback of the solve kernel.  -1 = follow the process default. */
 int hm_workspace_set_debug(hm_workspace_t ws, int split_render, int force_direct_solve);
-/* Instance groups of hm_optimize_batch (each group runs the kernel sequence on its own internal stream, so that one group's
- * under-filled iteration tail shares the chip with another group's main launch; results do not depend on it):
- * 0 = automatic (2 groups from 16 instances on), 1 = one stream as in rounds 1-3, up to 4. */
-int hm_workspace_set_groups(hm_workspace_t ws, int groups);
+/* (hm_workspace_set_groups moved to the product header in round 5: the drop-in Optimizer and bench.py use it.) */
 
 /* ---- performance-analysis aids (not part of the drop-in surface): when a device buffer is registered, block 0 of
  * the f16x3 decoder kernel / of the solve kernel writes shader-clock stamps per stage into it (scripts/gpu_trace_*.py). */

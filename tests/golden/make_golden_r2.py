@@ -181,6 +181,8 @@ def g16(ns):
     for name in GU.list_golden("g9_traj_"):
         g = GU.load(name)
         tag = name[len("g9_traj_"):]
+        if "lin8_bias_shift" in g.files:
+            continue                                   # round-5 cases: their noise rows are in g16_traj_noise_r5 (make_golden_r5.py)
         dname = str(g["decoder"])
         if dname not in decs:
             decs[dname] = ref_shim.build_reference_decoder(ns, GU.decoder_params(dname))

@@ -27,6 +27,21 @@ def decoder_params(name):
     return S.make_synthetic_decoder(**DEC_SPECS[str(name)])
 
 
+def decoder_params_for(g):
+    """Decoder parameters of a fixture: the seeded decoder `g['decoder']`, with `lin8.bias` raised by
+    `g['lin8_bias_shift']` when the fixture has that field (round-5 'no ray emitted' cases: a shrunken fruit)."""
+    p = decoder_params(g["decoder"])
+    if "lin8_bias_shift" in g.files:
+        p = {k: (v.copy() if hasattr(v, "copy") else v) for k, v in p.items()}
+        p["lin8.bias"] = (p["lin8.bias"] + np.float32(g["lin8_bias_shift"])).astype(np.float32)
+    return p
+
+
+def decoder_key(g):
+    """Cache key matching `decoder_params_for`."""
+    return (str(g["decoder"]), float(g["lin8_bias_shift"]) if "lin8_bias_shift" in g.files else 0.0)
+
+
 def cfg_from_golden(g):
     """Rebuild the nested `opt` config dict from the flattened 'cfg.*' entries."""
     o = {"lm": {}, "recon": {}, "render": {}, "weight": {}, "converge": {}}
@@ -76,8 +91,9 @@ def T(fp32_class, mixed):
 def traj_noise(tag):
     """(latent, T_ow, iter_count) deviation of the REFERENCE loop itself under a 1e-7 relative perturbation of the
     surface points (fixture g16, made by make_golden_r2.py from the imported reference): max over the two signs."""
-    g = load("g16_traj_noise")
-    if tag not in g.files:
-        return 0.0, 0.0, 0.0
-    a = np.abs(g[tag])
-    return float(a[:, 0].max()), float(a[:, 1].max()), float(a[:, 2].max())
+    for f in ("g16_traj_noise", "g16_traj_noise_r5"):
+        g = load(f)
+        if tag in g.files:
+            a = np.abs(g[tag])
+            return float(a[:, 0].max()), float(a[:, 1].max()), float(a[:, 2].max())
+    return 0.0, 0.0, 0.0

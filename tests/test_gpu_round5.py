@@ -1,0 +1,121 @@
+"""Round-5 GPU tests (run with `-m gpu`): behaviour added or un-deaded this round.  No module-level HM_PRECISION fixture
+here ON PURPOSE -- the first test needs the process default the drop-in class sees in a user's script."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _overflow_params():
+    """A decoder that is the SAME function in fp32 but whose layer-1 activations (~1e5) leave the fp16 range."""
+    from hortimapping_amd import synthetic as S
+    p = S.make_synthetic_decoder(32, seed=3, r0=0.04, aniso=(1.0, 0.75, 1.3))
+    big = {k: (v.copy() if hasattr(v, "copy") else v) for k, v in p.items()}
+    big["lin1.weight_g"] = big["lin1.weight_g"] * 4.0e6
+    big["lin2.weight_g"] = big["lin2.weight_g"] / 4.0e6
+    return p, big
+
+
+def _module(params, L=32):
+    from hortimapping_amd import synthetic as S
+
+    class Net(torch.nn.Module):                       # the reference passes an nn.Module (optimizer.py:17)
+        def __init__(self):
+            super().__init__()
+            for l, (o_, i_) in enumerate(S.layer_shapes(L)):
+                lin = torch.nn.Linear(i_, o_)
+                setattr(self, f"lin{l}", torch.nn.utils.weight_norm(lin) if l < 8 else lin)
+    net = Net()
+    net.load_state_dict({k: torch.from_numpy(np.asarray(v).copy()) for k, v in params.items()
+                         if k not in ("latent_dim", "hidden")}, strict=True)
+    return net
+
+
+def test_optimizer_from_module_defaults_to_f16x3_and_retries_by_itself(monkeypatch):
+    """`Optimizer(cfg, nn.Module)` with no HM_PRECISION in the environment (a user's script): the class selects f16x3 and
+    its own `retry_f32` turns an out-of-fp16-range decoder into the pure exact-f32 result, bit for bit; the decoder handle
+    the class owns keeps its f16x3 setting (the retry runs on the f32 twin)."""
+    monkeypatch.delenv("HM_PRECISION", raising=False)
+    from hortimapping_amd import optimizer as HO, synthetic as S, workloads as W
+    from hortimapping_amd.decoder import DecoderWeights
+    p, big = _overflow_params()
+    Ws, bs = S.fold_weight_norm(p)
+    insts = [W.to_instance(S.make_instance(Ws, bs, 32, i, n_pts=256, n_frames=1, n_fg=16, n_bg=16), pose_known=True)
+             for i in (1, 2)]
+    opt = W.c2_opt_cfg(max_iter=3)
+    pure = HO.optimize_batch(DecoderWeights.from_params(big).set_precision("f32"), opt, insts)
+    assert all(r.status == 8 and r.iter_count == 3 for r in pure)
+    o = HO.Optimizer({"device": "cuda", "opt": opt, "vis": {}}, _module(big))
+    assert o.decoder.precision == "f16x3"
+    for k, inst in enumerate(insts):
+        lat = inst.latent.clone()
+        z, T, n = o.shape_pose_joint_opt(lat, inst.T_ow, inst.render_data, inst.points_w, inst.cube_radius, None, True)
+        assert z is lat and n == 3
+        assert torch.equal(z.cpu(), pure[k].latent) and torch.equal(T.cpu(), pure[k].T_ow)
+        assert o.decoder.precision == "f16x3"
+    res = o.optimize_batch(insts)
+    assert all(r.retried_f32 for r in res) and all(torch.equal(a.latent, b.latent) for a, b in zip(res, pure))
+    # an in-range decoder through the same class: f16x3 results, nothing retried
+    o2 = HO.Optimizer({"device": "cuda", "opt": opt, "vis": {}}, _module(p))
+    r2 = o2.optimize_batch(insts)
+    ref = HO.optimize_batch(DecoderWeights.from_params(p).set_precision("f16x3"), opt, insts)
+    assert all((not a.retried_f32) and torch.equal(a.latent, b.latent) for a, b in zip(r2, ref))
+
+
+def test_mesh_grid_decode_falls_back_to_f32_per_instance():
+    """the entry points switch the shared decoder to f16x3 and the final voxel-grid decode ran in it too; a
+    poisoned tile would have put NaN into marching cubes and the .ply.  `MeshExtractor.decode_grids` now re-decodes the
+    instances with non-finite values in exact fp32 (on the f32 twin): the grid equals the pure-f32 grid bit for bit."""
+    from hortimapping_amd.decoder import DecoderWeights
+    from hortimapping_amd.mesher import MeshExtractor
+    p, big = _overflow_params()
+    lat = 0.05 * torch.randn(3, 32, generator=torch.Generator().manual_seed(1))
+    d32 = DecoderWeights.from_params(big).set_precision("f32")
+    g32 = MeshExtractor(d32, code_len=32, voxels_dim=24, cube_radius=0.08).decode_grids(lat)
+    dh = DecoderWeights.from_params(big).set_precision("f16x3")
+    mx = MeshExtractor(dh, code_len=32, voxels_dim=24, cube_radius=0.08)
+    gh = mx.decode_grids(lat)
+    assert torch.isfinite(gh).all() and torch.equal(gh, g32) and mx.n_f32_redecoded == 3
+    assert dh.precision == "f16x3"
+    meshes = mx.extract_meshes(lat)
+    assert all(m.vertices.shape[0] > 0 and np.isfinite(m.vertices).all() for m in meshes)
+    # in range: the f16x3 grid is used as it is
+    ok = DecoderWeights.from_params(p).set_precision("f16x3")
+    mo = MeshExtractor(ok, code_len=32, voxels_dim=24, cube_radius=0.08)
+    assert torch.isfinite(mo.decode_grids(lat)).all() and getattr(mo, "n_f32_redecoded", 0) == 0
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+def test_host_pacing_off_is_a_pure_enqueue_with_the_same_bits(precision):
+    """hm_workspace_set_host_pacing(ws, 0): with early exits possible the call must not wait for the device (it is then
+    legal under stream capture) and must give the same bits as the paced call."""
+    import time
+    from hortimapping_amd import optimizer as HO, synthetic as S, workloads as W
+    from hortimapping_amd.decoder import DecoderWeights
+    p = S.make_synthetic_decoder(32, seed=1, r0=0.04, aniso=(1.0, 0.75, 1.3))
+    Ws, bs = S.fold_weight_norm(p)
+    dec = DecoderWeights.from_params(p).set_precision(precision)
+    insts = [W.to_instance(S.make_instance(Ws, bs, 32, i, n_pts=512, n_frames=2, n_fg=64, n_bg=64)) for i in range(20)]
+    from oracle import hm_oracle as O
+    opt = O.default_opt_cfg()                       # wild_pepper.yaml block: every epsilon > 0, max_iter 50
+    opt["render"]["n_frame"] = 2
+    cache_a, cache_b = {}, {}
+    a = HO.optimize_batch(dec, opt, insts, cache=cache_a)
+    ws = HO._grown_workspace(dec, None, 20, 512, 2, 128, 30).set_host_pacing(False)
+    cache_b["ws"] = ws
+    torch.cuda.synchronize()
+    pb = HO.PackedBatch(insts, 32, 2, "cuda", F_cap=2, R_cap=128)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    HO.run_packed(ws, HO.opt_cfg_from_dict(opt), pb, 0)
+    t_enq = time.perf_counter() - t0
+    torch.cuda.synchronize()
+    t_all = time.perf_counter() - t0
+    assert all(1 < r.iter_count < 50 for r in a)                   # early exits really happen
+    for b, r in enumerate(a):
+        assert int(pb.iter_count[b]) == r.iter_count and int(pb.status[b]) == r.status
+        assert torch.equal(pb.latent[b].cpu(), r.latent) and torch.equal(pb.T_ow[b].cpu().reshape(4, 4), r.T_ow)
+    print(f"unpaced enqueue {t_enq * 1e3:.1f} ms of {t_all * 1e3:.1f} ms total")

@@ -6,8 +6,8 @@ import pytest
 import torch
 
 from oracle import hm_oracle as O
-from tests.golden_util import (cfg_from_golden, decoder_params, list_golden, load, relmax,
-                               render_data_from_golden)
+from tests.golden_util import (cfg_from_golden, decoder_key, decoder_params, decoder_params_for, list_golden, load,
+                               relmax, render_data_from_golden)
 
 _DEC = {}
 
@@ -121,7 +121,10 @@ def test_g8_one_iteration(name):
 
 
 def _run_traj(g):
-    d = dec(g["decoder"])
+    key = decoder_key(g)
+    if key not in _DEC:
+        _DEC[key] = O.fold_decoder(decoder_params_for(g))
+    d = _DEC[key]
     cfg = cfg_from_golden(g)
     z0, T0, pw = torch.from_numpy(g["latent0"]), torch.from_numpy(g["T_ow0"]), torch.from_numpy(g["points_w"])
     if str(g["kind"]) == "joint":

@@ -32,3 +32,24 @@ def test_oracle_matches_live_reference():
                                         rd, torch.from_numpy(inst["points_w"]), 0.08, pose_known=True)
     assert nr == no
     assert float((zo - zr).abs().max() / zr.abs().max()) < 1e-3 and float((To - Tr).abs().max()) < 1e-5
+
+
+def test_fuzz_slice_oracle_equals_live_reference():
+    """A 24-case slice of `scripts/fuzz_oracle_vs_reference.py` (round 5; the 300-case record is
+    profiles/r05_oracle_fuzz.txt): random small joint optimisations over every switch of the loop -- Sim(3)/SE(3),
+    linear/logistic occupancy, occlusion, the three LM variants, frames without foreground / background rays, frames that
+    return None, valid frames that emit zero rays, every exit branch -- the oracle must agree with the imported reference
+    on iter_count and exit branch exactly, on the emitted rays per iteration exactly, on H / b to 1e-5 and on the state to
+    1e-5 (or the reference's own conditioning noise, measured per case)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
+    import fuzz_oracle_vs_reference as F
+    from oracle import ref_shim
+    ns = ref_shim.import_reference()
+    bad = []
+    for seed in range(1000, 1024):
+        ok, rec = F.check_case(ns, seed)
+        if not ok:
+            bad.append((seed, rec["fails"], rec["iter"], rec["reason"]))
+    assert not bad, bad
