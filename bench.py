@@ -235,7 +235,7 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="c2_joint", choices=["c2_joint", "c2_sdf"])
+    ap.add_argument("--workload", default="c2_joint", choices=["c2_joint", "c2_sdf", "c2_joint2048"])
     ap.add_argument("--batch", type=int, default=0,
                     help="instances per GPU per step (weak scaling, default 64) or chunk size (--total, default 256)")
     ap.add_argument("--total", type=int, default=0,
@@ -320,7 +320,8 @@ def main(argv=None, emit=True):
     dev = torch.device("cpu") if stub else torch.device("cuda", local_rank)
 
     L = args.latent
-    kind = "joint" if args.workload == "c2_joint" else "sdf"
+    kind = "sdf" if args.workload == "c2_sdf" else "joint"
+    inst_kind = "joint2048" if args.workload == "c2_joint2048" else kind
     strong = args.total > 0
     per_gpu = args.batch or 64
     chunk = args.batch or 256
@@ -357,7 +358,7 @@ def main(argv=None, emit=True):
         cfg = W.c2_opt_cfg(max_iter=args.iters, n_sample_on_ray=16, n_frame=1)
         hcfg = HO.opt_cfg_from_dict(cfg)
         need = sorted({i % DISTINCT for i in ids}) if strong else ids
-        made = dict(zip(need, W.make_c2_instances(params, dec, need, kind=kind, device=dev)))
+        made = dict(zip(need, W.make_c2_instances(params, dec, need, kind=inst_kind, device=dev)))
         dicts = [made[i % DISTINCT if strong else i] for i in ids]
         insts = [W.to_instance(d) for d in dicts]
         pbs = [HO.PackedBatch(insts[lo:hi], L, 1, dev, joint=not shape_only) for lo, hi in chunks]
@@ -458,7 +459,7 @@ def main(argv=None, emit=True):
         achieved = flops / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
         traffic, tsrc, busy = None, None, None    # HBM/fabric bytes per launch: from committed PMC passes of the same workload
         tj = os.path.join(ROOT, TRAFFIC_FILE) if TRAFFIC_FILE else None
-        if kind == "joint" and not strong and per_gpu == 64 and L == 256 and args.decoder == "analytic" and tj and os.path.exists(tj):
+        if args.workload == "c2_joint" and not strong and per_gpu == 64 and L == 256 and args.decoder == "analytic" and tj and os.path.exists(tj):
             tj_ = json.load(open(tj)).get(precision, {})
             traffic, busy = tj_.get("bytes_per_launch"), tj_.get("mfma_pipe_busy_frac")
             if traffic is not None:
@@ -525,6 +526,10 @@ def main(argv=None, emit=True):
     if rank == 0:
         joint_txt = ("256-dim latent, 8x512 DeepSDF decoder, joint latent + Sim(3) pose LM, 1024 surface pts + 1 frame "
                      "x 64 rays x 16 samples (2048 decoder pts/iteration), %d forced iterations" % args.iters)
+        if inst_kind == "joint2048":
+            joint_txt = ("256-dim latent, 8x512 DeepSDF decoder, joint latent + Sim(3) pose LM, 2048 SURFACE pts + 1 frame "
+                         "x 64 rays x 16 samples (3072 decoder pts/iteration: the literal '2048 pts/instance' reading of "
+                         "the joint loop), %d forced iterations" % args.iters)
         sdf_txt = ("256-dim latent, 8x512 DeepSDF decoder, shape-only LM (shape_opt_deepsdf), 2048 surface pts, "
                    "%d forced iterations" % args.iters)
         head = (f"{args.workload}: {n_total} synthetic peppers in total ({DISTINCT} distinct, replicated), sharded over "
@@ -574,7 +579,7 @@ def main(argv=None, emit=True):
                         "diff_note": "free-pose 200-iteration trajectories amplify rounding noise; per-instance parity of "
                                      "every arithmetic vs the CPU oracle: profiles/r03_parity_fullsize_*.txt"}
     if (not stub and not args.no_exact and world == 1 and not strong and args.decoder == "analytic" and L == 256
-            and kind == "joint" and per_gpu == 64):
+            and args.workload == "c2_joint" and per_gpu == 64):
         # the same job on TRAINED decoder weights (dense layers instead of the near-identity analytic ones: different
         # operand statistics for the matrix cores and the socket power limit), one timed step
         o2 = main(["--steps", "3", "--warmup", "1", "--iters", str(args.iters), "--decoder", "trained", "--precision",
@@ -595,6 +600,13 @@ def main(argv=None, emit=True):
                    args.precision, "--no-exact", "--no-cpu-baseline", "--groups", str(args.groups)], emit=False)
         out["c2_sdf"] = {"value": o4["value"], "unit": o4["unit"], "steps": 3, "dtype": o4["dtype"],
                          "ms_per_step": o4["ms_per_step"], "workload": o4["config"]["workload"], "roofline": o4["roofline"]}
+        # the literal reading of "latent + 7-DoF pose ... 2048 pts/instance": the JOINT loop on 2048 surface points plus the
+        # 64 x 16 render block (VERDICT r04 missing #4)
+        o6 = main(["--steps", "3", "--warmup", "1", "--iters", str(args.iters), "--workload", "c2_joint2048", "--precision",
+                   args.precision, "--no-exact", "--no-cpu-baseline", "--groups", str(args.groups)], emit=False)
+        out["c2_joint2048"] = {"value": o6["value"], "unit": o6["unit"], "steps": 3, "dtype": o6["dtype"],
+                               "ms_per_step": o6["ms_per_step"], "workload": o6["config"]["workload"],
+                               "roofline": o6["roofline"]}
         # BASELINE.json configs[3] as ONE rank of eight sees it: 512 of the 4096 instances, two chunks of 256 through one
         # workspace (the strong-scaling job is `bench.py --gpus 8 --total 4096`)
         o5 = main(["--steps", "3", "--warmup", "1", "--iters", str(args.iters), "--total", "512", "--batch", "256",

@@ -13,6 +13,9 @@ constexpr int TQ = 64;          // decoder queries per workgroup tile (2 MFMA N-
 constexpr int NWAVE = 8;        // waves per decoder workgroup
 constexpr int NSTAGE = 16;      // 8 forward GEMM stages (lin0..lin7; lin8 is a VALU dot) + 8 backward
 constexpr int POSE_PAD = 8;     // pose columns reserved in a Jacobian row
+// Default margin [m] of the linear-occupancy screening (hm_render.hip k_promote): bound on |sdf_fp16 - sdf_f16x3| with
+// room to spare.  Measured (scripts/measure_screen_eps.py, profiles/r05_screen_eps.txt): see DESIGN.md section 4.
+constexpr float HM_SCREEN_EPS_DEFAULT = 1.0e-3f;
 constexpr int MAX_L = 256;
 
 // epilogue kinds of a decoder stage

@@ -53,7 +53,17 @@ struct RenderCfg {
   int log_occ, occlusion_on, scale_on;
   float occ_th, occlusion_th, min_grad;
   int min_valid;
+  // LINEAR-occupancy screening (round 5; hm_render.hip k_promote): 0 off; 1 on; 2 on + verify against a full f16x3
+  // forward (rb.sdfFull).  A ray sample whose one-pass fp16 sdf lies beyond occ_th + screen_eps is "far": its occupancy is
+  // exactly 0 or 1 whatever its exact sdf (utils.py:125-133 clamps), so only the others go through the f16x3 forward.
+  int screen;
+  float screen_eps;
 };
+
+// cpos codes of screened-far samples (instead of a slot in the promoted list)
+constexpr int CPOS_NOT_VALID = -1;   // outside the ball (loss.py:38)
+constexpr int CPOS_FAR_INSIDE = -2;  // sdf < -occ_th for certain (or behind such a sample on its ray): occupancy 1
+constexpr int CPOS_FAR_OUTSIDE = -3; // sdf > +occ_th for certain: occupancy 0
 
 struct RenderBuffers {
   // caller inputs
@@ -89,6 +99,13 @@ struct RenderBuffers {
   float* yG;               // [B][nG_stride]
   int* srcG;               // [B][nG_stride]   slot (index in ptsRc / sdfR order) each Jacobian sample was gathered from
   void* maskR;             // [B][nR_stride / 64][8][512] uint2: ReLU masks saved by the f16x3 forward pass over ptsRc
+  // screening (RenderCfg::screen): fp16 sdf of every ball-valid sample, the promoted samples the f16x3 forward decodes
+  // instead of ptsRc (cpos then indexes THIS list), their count, and the per-group statistics
+  float* sdfS;             // [B][nR_stride]     one-pass fp16 sdf, ptsRc slot order
+  float* ptsRp;            // [B][nR_stride][4]  promoted samples
+  int* nRp;                // [B]
+  const float* sdfFull;    // verify mode: f16x3 sdf of EVERY ball-valid sample, ptsRc slot order (else nullptr)
+  unsigned long long* screen_stats;  // [4]: screened, promoted, violations (verify mode), dead (behind a far-inside sample)
   float* JR;               // [B][2*F*R][ldJ]   depth rows then mask rows
   int nR_stride, nG_stride;
 };
@@ -131,6 +148,8 @@ int launch_transform_points(const float* d_points_w, int n_in_stride, const int*
 
 int launch_render_front(const RenderCfg& cfg, const RenderBuffers& rb, const float* d_T_ow, const int* d_active,
                         int B, hipStream_t stream, const float* d_frame_override = nullptr);   // frame setup + ray sampling
+int launch_render_promote(const RenderCfg& cfg, const RenderBuffers& rb, const int* d_active, int B,
+                          hipStream_t stream);               // screening: far / promoted split of the ball-valid samples
 int launch_render_scan(const RenderCfg& cfg, const RenderBuffers& rb, const int* d_active, int B,
                        hipStream_t stream);                  // ray scan + offsets + scatter
 int launch_render_reduce(const RenderCfg& cfg, const RenderBuffers& rb, const int* d_active, int B, int L,

@@ -64,6 +64,12 @@ struct hm_workspace_s {
   // buffer), so it is allocated on the first call that takes the fused path, not for f32 / plain-fp16 / shape-only use
   void* d_maskR;
   size_t maskR_bytes;
+  // linear-occupancy screening (hm_workspace_set_screening): 0 off, 1 on (default), 2 on + verify; margin eps [m]
+  int screen_mode;
+  float screen_eps;
+  float* d_sdfFull;               // verify mode only: f16x3 sdf of every ball-valid sample (lazy, like the masks)
+  size_t sdfFull_bytes;
+  unsigned long long* d_screen_stats;   // [G_MAX][4]
 };
 
 // hm_workspace_counters_read layout
@@ -102,6 +108,7 @@ void carve(hm_workspace_s* w, Carver& c) {
   const size_t nray = F * R, nS = w->nS_stride, nR = w->nR_stride, nG = w->nG_stride, ldJ = w->ldJ;
   c.take_group(w->d_act_count, hm_workspace_s::N_ACT);
   c.take_group(w->d_counters, N_COUNTER);
+  c.take_group(w->d_screen_stats, 4);
   c.take(w->c0, HID, B);
   c.take(w->c4, HID, B);
   c.take(w->ptsS, nS * 4, B);
@@ -135,11 +142,17 @@ void carve(hm_workspace_s* w, Carver& c) {
   c.take(rb.yG, nG, B);
   c.take(rb.srcG, nG, B);
   c.take(rb.JR, 2 * nray * ldJ, B);
+  c.take(rb.sdfS, nR, B);
+  c.take(rb.ptsRp, nR * 4, B);
+  c.take(rb.nRp, 1, B);
   // ReLU masks of the f16x3 forward pass over the ray samples: a separate, lazy allocation (begin_call)
   if (c.mode == Carver::VIEW) {
     if (w->d_maskR) w->d_maskR = static_cast<char*>(w->d_maskR) + (size_t)c.b0 * (nR / TQ) * 8 * 512 * sizeof(unsigned long long);
   }
+  if (c.mode == Carver::VIEW && w->d_sdfFull) w->d_sdfFull += (size_t)c.b0 * nR;
   rb.maskR = w->d_maskR;
+  rb.sdfFull = nullptr;                                  // set per call (verify mode)
+  rb.screen_stats = w->d_screen_stats;
   rb.nR_stride = w->nR_stride;
   rb.nG_stride = w->nG_stride;
 }
@@ -245,6 +258,9 @@ RenderCfg make_render_cfg(const hm_workspace_s* ws, const hm_opt_cfg* cfg) {
   rc.log_occ = cfg->log_sdf_occ; rc.occlusion_on = cfg->occlusion_on; rc.scale_on = cfg->scale_on;
   rc.occ_th = cfg->occ_cutoff; rc.occlusion_th = cfg->occlusion_th; rc.min_grad = cfg->min_grad_thre;
   rc.min_valid = cfg->min_valid_sample;
+  // screening applies to the f16x3 render chain under LINEAR occupancy only (logistic occupancy never saturates exactly)
+  rc.screen = ((ws->dec->precision == 1 || ws->dec->precision == 2) && !ws->split_render && !cfg->log_sdf_occ) ? ws->screen_mode : 0;
+  rc.screen_eps = ws->screen_eps;
   return rc;
 }
 
@@ -260,6 +276,20 @@ void bind_inputs(RenderBuffers& rb, const hm_batch* bt) {
 int g_split_render = 0;
 
 bool fused_path(const hm_workspace_s* ws) { return (ws->dec->precision == 1 || ws->dec->precision == 2) && !ws->split_render; }
+
+// Screening of the ball-valid ray samples (linear occupancy, f16x3 chain; hm_render.hip k_promote): one-pass fp16 forward
+// over all of them, then the far / promoted split.  Afterwards the f16x3 forward decodes rb.ptsRp / rb.nRp.
+int screen_pass(hm_workspace_s* ws, const RenderCfg& rc, RenderBuffers& rb, int B, const int* d_active, hipStream_t st) {
+  int rc_ = launch_decoder_p(ws->dec, B, rb.ptsRc, rb.nRq, d_active, ws->nR_stride, ws->c0, ws->c4, rb.sdfS, nullptr, 0, 0, 0, st, 0);
+  if (rc_) return rc_;
+  rb.sdfFull = nullptr;
+  if (rc.screen == 2) {     // verify: the exact forward over EVERY ball-valid sample, compared inside k_promote
+    rc_ = launch_decoder_h(ws->dec, B, rb.ptsRc, rb.nRq, d_active, ws->nR_stride, ws->c0, ws->c4, ws->d_sdfFull, nullptr, 0, 0, 0, st, 2);
+    if (rc_) return rc_;
+    rb.sdfFull = ws->d_sdfFull;
+  }
+  return launch_render_promote(rc, rb, d_active, B, st);
+}
 
 // render chain after the forward pass: scan / offsets / scatter, Jacobian pass, per-ray reduce (optimizer.py:93-132)
 int render_back(hm_workspace_s* ws, const RenderCfg& rc, const RenderBuffers& rb, const hm_batch* bt, int P,
@@ -277,12 +307,19 @@ int render_back(hm_workspace_s* ws, const RenderCfg& rc, const RenderBuffers& rb
 }
 
 // render front end + forward pass + the above, for the current state (the functional render API)
-int render_pass(hm_workspace_s* ws, const RenderCfg& rc, const RenderBuffers& rb, const hm_batch* bt, int P,
+int render_pass(hm_workspace_s* ws, const RenderCfg& rc, const RenderBuffers& rb_in, const hm_batch* bt, int P,
                 const int* d_active, hipStream_t st, const float* d_frame_override = nullptr) {
   const int B = bt->B;
+  RenderBuffers rb = rb_in;
+  if (!(ws->count_on || rc.screen == 2)) rb.screen_stats = nullptr;
   int rc_ = launch_render_front(rc, rb, bt->d_T_ow, d_active, B, st, d_frame_override);
   if (rc_) return rc_;
-  if (fused_path(ws))
+  if (fused_path(ws) && rc.screen) {
+    rc_ = screen_pass(ws, rc, rb, B, d_active, st);
+    if (rc_) return rc_;
+    rc_ = launch_decoder_h_fwd_masks(ws->dec, B, d_active, ws->c0, ws->c4, rb.ptsRp, rb.nRp, ws->nR_stride, rb.sdfR,
+                                     rb.maskR, st);
+  } else if (fused_path(ws))
     rc_ = launch_decoder_h_fwd_masks(ws->dec, B, d_active, ws->c0, ws->c4, rb.ptsRc, rb.nRq, ws->nR_stride, rb.sdfR,
                                      rb.maskR, st);
   else
@@ -320,6 +357,13 @@ int begin_call(hm_workspace_s* ws, int joint) {
       ws->d_maskR = nullptr; ws->maskR_bytes = 0; return -2; }
     ws->rb.maskR = ws->d_maskR;
   }
+  if (joint && fused_path(ws) && ws->screen_mode == 2 && ws->d_sdfFull == nullptr) {
+    ws->sdfFull_bytes = (size_t)ws->lim.max_batch * ws->nR_stride * sizeof(float);
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&ws->d_sdfFull), ws->sdfFull_bytes);
+    if (e != hipSuccess) {
+      hm_set_error("hipMalloc(%zu) of the screening verify buffer failed: %s", ws->sdfFull_bytes, hipGetErrorString(e));
+      ws->d_sdfFull = nullptr; ws->sdfFull_bytes = 0; return -2; }
+  }
   return 0;
 }
 }  // namespace
@@ -333,6 +377,7 @@ extern "C" int hm_workspace_create(hm_decoder_s* dec, const hm_limits* lim, hm_w
   w->profile_on = 0; w->ev_used = 0; w->d_blob = nullptr; w->blob_bytes = 0; w->count_on = 0;
   w->dbg_split_override = w->dbg_direct_override = -1; w->split_render = w->force_direct = 0;
   w->d_maskR = nullptr; w->maskR_bytes = 0;
+  w->screen_mode = 1; w->screen_eps = HM_SCREEN_EPS_DEFAULT; w->d_sdfFull = nullptr; w->sdfFull_bytes = 0;
   w->dec = dec; w->lim = *lim; w->L = dec->L; w->ldJ = dec->L + POSE_PAD;
   if (w->lim.max_frames == 0 || w->lim.max_rays == 0 || w->lim.max_samples == 0) {
     w->lim.max_frames = 1; w->lim.max_rays = 1; w->lim.max_samples = 2;     // shape-only workspace
@@ -461,11 +506,37 @@ extern "C" int hm_workspace_destroy(hm_workspace_s* w) {
   if (w->have_fork) (void)hipEventDestroy(w->ev_fork);
   (void)hipFree(w->d_blob);
   if (w->d_maskR) (void)hipFree(w->d_maskR);
+  if (w->d_sdfFull) (void)hipFree(w->d_sdfFull);
   delete w;
   return 0;
 }
 
-extern "C" size_t hm_workspace_bytes(hm_workspace_s* w) { return w ? w->blob_bytes + w->maskR_bytes : 0; }
+extern "C" size_t hm_workspace_bytes(hm_workspace_s* w) { return w ? w->blob_bytes + w->maskR_bytes + w->sdfFull_bytes : 0; }
+
+extern "C" int hm_workspace_set_screening(hm_workspace_s* w, int mode, float eps) {
+  if (w == nullptr) { hm_set_error("null workspace"); return -1; }
+  if (mode < 0 || mode > 2) { hm_set_error("screening mode must be 0 (off), 1 (on) or 2 (on + verify)"); return -1; }
+  if (eps < 0.f) { hm_set_error("screening margin must be >= 0 (0 selects the default)"); return -1; }
+  w->screen_mode = mode;
+  w->screen_eps = eps > 0.f ? eps : HM_SCREEN_EPS_DEFAULT;
+  return 0;
+}
+
+extern "C" int hm_workspace_screening_stats(hm_workspace_s* w, int reset, long long* out4, void* stream) {
+  if (w == nullptr) { hm_set_error("null argument"); return -1; }
+  constexpr int N = hm_workspace_s::G_MAX * 4;
+  if (out4 != nullptr) {
+    HM_CHECK_HIP(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+    long long all[N];
+    HM_CHECK_HIP(hipMemcpy(all, w->d_screen_stats, sizeof(all), hipMemcpyDeviceToHost));
+    for (int k = 0; k < 4; ++k) {
+      out4[k] = 0;
+      for (int g = 0; g < hm_workspace_s::G_MAX; ++g) out4[k] += all[g * 4 + k];
+    }
+  }
+  if (reset) HM_CHECK_HIP(hipMemset(w->d_screen_stats, 0, N * sizeof(unsigned long long)));
+  return 0;
+}
 
 namespace {
 
@@ -522,6 +593,8 @@ int opt_begin(OptRun& r, const hm_opt_cfg* cfg) {
   r.rcfg = make_render_cfg(ws, cfg);
   r.rb = ws->rb;
   if (r.mode == 0) { bind_inputs(r.rb, bt); r.rb.status = bt->d_status; }
+  // screening statistics cost three atomics per ray: only with the work counters on, or in verify mode
+  if (!(r.owner->count_on || r.rcfg.screen == 2)) r.rb.screen_stats = nullptr;
   // Early stop of the LAUNCH loop.  Finished instances are frozen on the device (`active` flags), so results never depend
   // on this; but a batch whose instances have all converged by iteration 7 of max_iter 50 would still be sent 43 x 13
   // launches that find nothing to do (~4 us each: 2-3 ms, more than the work itself for a single fruit).  After every
@@ -545,7 +618,7 @@ int opt_iteration(OptRun& r, const hm_opt_cfg* cfg, int it, hipEvent_t after_mai
   const hm_batch* bt = &r.bt;
   const hm_debug* dbg = r.dbg;
   const RenderCfg& rcfg = r.rcfg;
-  const RenderBuffers& rb = r.rb;
+  RenderBuffers& rb = r.rb;
   hipStream_t st = r.st;
   const int B = bt->B, L = ws->L, mode = r.mode, P = r.P;
   constexpr int LAG = 2, N_ACT = hm_workspace_s::N_ACT;
@@ -575,7 +648,12 @@ int opt_iteration(OptRun& r, const hm_opt_cfg* cfg, int it, hipEvent_t after_mai
     if (fused) rc = launch_render_front(rcfg, rb, bt->d_T_ow, ws->active, B, st);
     else rc = render_pass(ws, rcfg, rb, bt, P, ws->active, st);
     if (rc) return rc;
+    if (fused && rcfg.screen) {
+      rc = screen_pass(ws, rcfg, rb, B, ws->active, st);
+      if (rc) return rc;
+    }
   }
+  const bool screened = fused && rcfg.screen;
   rc = launch_transform_points(bt->d_points_w, bt->points_stride, bt->d_n_points, bt->d_T_ow, ws->active, B,
                                ws->nS_stride, ws->ptsS, st);
   if (rc) return rc;
@@ -593,7 +671,8 @@ int opt_iteration(OptRun& r, const hm_opt_cfg* cfg, int it, hipEvent_t after_mai
   }
   if (fused)     // ONE grid: SDF-term forward+backward tiles, then the forward-only tiles of the ray samples
     rc = launch_decoder_h_main(ws->dec, B, ws->active, ws->c0, ws->c4, ws->ldJ, ws->ptsS, bt->d_n_points, ws->nS_stride,
-                               ws->yS, ws->JS, P, rb.ptsRc, rb.nRq, ws->nR_stride, rb.sdfR, rb.maskR, st);
+                               ws->yS, ws->JS, P, screened ? rb.ptsRp : rb.ptsRc, screened ? rb.nRp : rb.nRq, ws->nR_stride,
+                               rb.sdfR, rb.maskR, st);
   else
     rc = launch_decoder(ws->dec, B, ws->ptsS, bt->d_n_points, ws->active, ws->nS_stride, ws->c0, ws->c4, ws->yS,
                         ws->JS, ws->ldJ, P == 0 ? 6 : P, 1, st, 0);

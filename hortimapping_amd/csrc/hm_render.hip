@@ -6,6 +6,9 @@
 //   k_frame_setup      optimizer.py:66,103-111   T_oc, depth window, per-frame constants
 //   k_sample_rays      loss.py:30-40             p_c = dir * d_j, p_o = R_oc p_c + t_oc, ball filter (+ count for :43-45)
 //   (K1 forward-only on the ball-valid samples)   loss.py:48-49
+//   [k_promote         linear occupancy only: one-pass fp16 screening of the ball-valid samples; only the ones that may
+//                      lie in the +-cutoff band (utils.py:125-133 clamps the others to exactly 0 / 1) go through the
+//                      fp32-class forward -- round 5]
 //   k_ray_scan         loss.py:55-176            occupancy, transmittance scan, d_u, occ_ray, de/do, dm/do, do/ds,
 //                                                min-grad and occlusion filters, residuals
 //   k_ray_offsets      loss.py:160-166           torch.unique(ray ids) == ascending ray order -> prefix sums
@@ -61,7 +64,7 @@ __global__ void k_frame_setup(const RenderCfg cfg, const RenderBuffers rb, const
   if (active != nullptr && active[b] == 0) return;
   const int f = threadIdx.x;
   const int nf = rb.n_frames[b];
-  if (f == 0) { rb.nRq[b] = 0; rb.nflag[b] = 0; }   // k_sample_rays counts the ball-valid samples into nRq
+  if (f == 0) { rb.nRq[b] = 0; rb.nflag[b] = 0; if (rb.nRp != nullptr) rb.nRp[b] = 0; }   // k_sample_rays counts the ball-valid samples into nRq
   if (f >= cfg.F) return;
   rb.valid_count[b * cfg.F + f] = 0;
   if (f >= nf) return;
@@ -147,6 +150,82 @@ __global__ __launch_bounds__(256) void k_sample_rays(const RenderCfg cfg, const 
   rb.cpos[at] = slot;
 }
 
+// LINEAR-occupancy screening (RenderCfg::screen; round 5).  sdf_to_occupancy (utils.py:125-133) clamps: a sample with
+// sdf >= +th has occupancy exactly 0, one with sdf <= -th exactly 1, and neither is a with-grad sample (loss.py:66) --
+// whatever its exact value.  So the exact (fp32-class, three-pass) forward is only needed for samples that MAY lie inside
+// the band.  Every ball-valid sample has been decoded by the ONE-pass fp16 forward (K1p, half the cost per pass and a
+// third of the passes) into sdfS; with |s_fp16 - s| <= eps (measured bound with margin, scripts/measure_screen_eps.py):
+//   s_fp16 >  th + eps  ->  s >  th: far outside, occupancy 0
+//   s_fp16 < -th - eps  ->  s < -th: far inside,  occupancy 1
+//   otherwise (or not finite)      : PROMOTED to the f16x3 forward (+ ReLU masks), exactly as before.
+// Behind the first far-inside sample of a ray the transmittance is exactly 0 (loss.py:81: cumprod of 1 - o with an
+// o == 1 factor), so every later sample of that ray has term_prob == 0, contributes 0 to d_u / occ_ray / the suffix sums
+// and fails `de_do > min_grad_thre` (0 or 0/0): its value cannot reach any output bit and it is not promoted either
+// ("dead").  One wavefront per ray, lane = depth sample; cpos is rewritten from "slot in ptsRc" to "slot in the promoted
+// list ptsRp" or a CPOS_FAR_* code that k_ray_scan turns into a saturated sdf.  Bit-identical results by construction;
+// tests/test_gpu_round5.py compares whole trajectories with the screening off and counts violations in verify mode.
+__global__ __launch_bounds__(256) void k_promote(const RenderCfg cfg, const RenderBuffers rb,
+                                                 const int* __restrict__ active) {
+  const int b = blockIdx.z, f = blockIdx.y;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (r >= cfg.R) return;
+  if (active != nullptr && active[b] == 0) return;
+  if (f >= rb.n_frames[b]) return;
+  const int nray = rb.n_fg[b * cfg.F + f] + rb.n_bg[b * cfg.F + f];
+  if (r >= nray) return;
+  // a frame with too few ball-valid samples is skipped by k_ray_scan (loss.py:43-45): none of its samples is needed
+  const bool frame_ok = rb.valid_count[b * cfg.F + f] >= cfg.min_valid;
+  const int M = cfg.M;
+  const size_t at = (size_t)b * rb.nR_stride + (size_t)(f * cfg.R + r) * M + lane;
+  const bool in = lane < M;
+  f32x4 p = {0, 0, 0, 0};
+  int slot = CPOS_NOT_VALID;
+  if (in) { p = reinterpret_cast<const f32x4*>(rb.ptsR)[at]; slot = rb.cpos[at]; }
+  const bool valid = in && p[3] != 0.f && slot >= 0;
+  const float st = valid ? rb.sdfS[(size_t)b * rb.nR_stride + slot] : 0.f;
+  const float lim = cfg.occ_th + cfg.screen_eps;
+  const bool far_in = valid && st < -lim, far_out = valid && st > lim;
+  const unsigned long long m_in = __ballot(far_in);
+  const int first_in = m_in ? __ffsll((long long)m_in) - 1 : 64;
+  // (a sample whose screening value is not finite is never dead: it is promoted, so that the range guard of the f16x3
+  // forward reports it exactly as it did before the screening existed)
+  const bool dead = valid && lane > first_in && isfinite(st);
+  const bool promote = valid && frame_ok && !dead && !far_in && !far_out;     // includes non-finite screening values
+  const unsigned long long pm = __ballot(promote);
+  int base = 0;
+  if (pm != 0ull) {
+    if (lane == 0) base = atomicAdd(&rb.nRp[b], __popcll(pm));
+    base = __shfl(base, 0);
+  }
+  if (valid) {
+    int code;
+    if (promote) {
+      code = base + __popcll(pm & ((1ull << lane) - 1ull));
+      reinterpret_cast<f32x4*>(rb.ptsRp)[(size_t)b * rb.nR_stride + code] = p;
+    } else {
+      code = (far_in || dead) ? CPOS_FAR_INSIDE : (far_out ? CPOS_FAR_OUTSIDE : CPOS_FAR_OUTSIDE);
+      // (!frame_ok: the code is never read)
+    }
+    rb.cpos[at] = code;
+  }
+  if (rb.screen_stats != nullptr) {
+    bool bad = false;
+    if (rb.sdfFull != nullptr && valid && frame_ok && !promote) {
+      const float ex = rb.sdfFull[(size_t)b * rb.nR_stride + slot];
+      if (far_in && lane == first_in) bad = !(ex < -cfg.occ_th);             // must really saturate to occupancy 1
+      else if (!dead && !far_in) bad = !(ex > cfg.occ_th);                   // far outside: must really be occupancy 0
+    }
+    const unsigned long long vm = __ballot(valid && frame_ok), dm = __ballot(dead && frame_ok), bm = __ballot(bad);
+    if (lane == 0) {
+      atomicAdd(&rb.screen_stats[0], (unsigned long long)__popcll(vm));
+      atomicAdd(&rb.screen_stats[1], (unsigned long long)__popcll(pm));
+      if (bm) atomicAdd(&rb.screen_stats[2], (unsigned long long)__popcll(bm));
+      if (dm) atomicAdd(&rb.screen_stats[3], (unsigned long long)__popcll(dm));
+    }
+  }
+}
+
 // one wavefront per ray, lane = depth sample
 __global__ __launch_bounds__(256) void k_ray_scan(const RenderCfg cfg, const RenderBuffers rb,
                                                   const int* __restrict__ active) {
@@ -178,7 +257,9 @@ __global__ __launch_bounds__(256) void k_ray_scan(const RenderCfg cfg, const Ren
   if (in) {
     valid = rb.ptsR[(sbase + lane) * 4 + 3] != 0.f;
     const int slot = rb.cpos[sbase + lane];
-    s = slot >= 0 ? rb.sdfR[(size_t)b * rb.nR_stride + slot] : 0.f;
+    // screened-far samples (k_promote) carry a code instead of a slot: any sdf beyond the clamp gives the same bits
+    s = slot >= 0 ? rb.sdfR[(size_t)b * rb.nR_stride + slot]
+                  : (slot == CPOS_FAR_INSIDE ? -1e30f : (slot == CPOS_FAR_OUTSIDE ? 1e30f : 0.f));
     if (valid && !isfinite(s)) rb.nflag[b] = 1;                 // reported by the solver as a numerical failure
     dj = linspace_at(d_min, d_max, M, lane);
     if (valid) {
@@ -352,6 +433,14 @@ int launch_render_front(const RenderCfg& cfg, const RenderBuffers& rb, const flo
   HM_CHECK_HIP(hipGetLastError());
   dim3 grid((cfg.R * cfg.M + 255) / 256, cfg.F, B);
   hipLaunchKernelGGL(k_sample_rays, grid, dim3(256), 0, stream, cfg, rb, d_active);
+  HM_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_render_promote(const RenderCfg& cfg, const RenderBuffers& rb, const int* d_active, int B,
+                          hipStream_t stream) {
+  dim3 grid((cfg.R + 3) / 4, cfg.F, B);
+  hipLaunchKernelGGL(k_promote, grid, dim3(256), 0, stream, cfg, rb, d_active);
   HM_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -196,9 +196,16 @@ def synthetic_scene(params, sdf_fn_factory, n_fruits=3, seed=7, r_max=0.08):
     L = int(params["latent_dim"])
     Ws, bs = S.fold_weight_norm(params)
     fruits = []
+    cols = n_fruits if n_fruits <= 6 else int(np.ceil(np.sqrt(n_fruits * 1.5)))     # a row, or a cols x rows wall of fruits
+    rows = (n_fruits + cols - 1) // cols
     for i in range(n_fruits):
         z_true = (0.07 * rs.randn(L)).astype(np.float32)
-        centre = np.array([0.16 * (i - (n_fruits - 1) / 2), 0.02 * rs.randn(), 0.5 + 0.03 * rs.randn()])
+        if rows == 1:
+            centre = np.array([0.16 * (i - (n_fruits - 1) / 2), 0.02 * rs.randn(), 0.5 + 0.03 * rs.randn()])
+        else:                  # 12 cm pitch at 0.6 m: every fruit stays inside a 720 x 1280 image of the f = 300 px camera
+            cx, cy = i % cols, i // cols
+            centre = np.array([0.12 * (cx - (cols - 1) / 2) + 0.005 * rs.randn(), 0.12 * (cy - (rows - 1) / 2) + 0.005 * rs.randn(),
+                               0.6 + 0.02 * rs.randn()])
         f_obj = sdf_fn_factory(z_true) if sdf_fn_factory else (lambda p, z=z_true: S.np_decoder_forward(Ws, bs, z, p))
         fruits.append({"z_true": z_true, "centre": centre,
                        "sdf_world": (lambda p, c=centre, f=f_obj: f(p - c))})

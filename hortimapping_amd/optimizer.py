@@ -164,6 +164,23 @@ class Workspace:
         _lib.check(lib.hm_workspace_set_host_pacing(self.handle, 1 if on else 0), "hm_workspace_set_host_pacing")
         return self
 
+    def set_screening(self, mode: int, eps: float = 0.0):
+        """Linear-occupancy screening of the ray samples (include/hortimapping_amd.h): 0 off, 1 on (default), 2 on + verify."""
+        lib = _lib.lib()
+        lib.hm_workspace_set_screening.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_float]
+        _lib.check(lib.hm_workspace_set_screening(self.handle, int(mode), float(eps)), "hm_workspace_set_screening")
+        return self
+
+    def screening_stats(self, reset: bool = True) -> dict:
+        """{'screened', 'promoted', 'violations', 'dead'} summed since the last reset (needs counters on or verify mode)."""
+        lib = _lib.lib()
+        lib.hm_workspace_screening_stats.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_longlong),
+                                                     ctypes.c_void_p]
+        out = (ctypes.c_longlong * 4)()
+        _lib.check(lib.hm_workspace_screening_stats(self.handle, 1 if reset else 0, out, ctypes.c_void_p(_stream())),
+                   "hm_workspace_screening_stats")
+        return dict(zip(("screened", "promoted", "violations", "dead"), (int(v) for v in out)))
+
     def set_groups(self, groups: int):
         """Instance groups per optimisation call (internal streams): 0 = automatic, 1 = one stream, up to 4.  Results do
         not depend on it (include/hortimapping_amd.h)."""

@@ -66,3 +66,38 @@ def get_rays(sampled_pixels, invK):
     n = sampled_pixels.shape[0]
     u_hom = np.concatenate([sampled_pixels, np.ones((n, 1))], axis=-1)
     return (u_hom[:, None, :] * invK).sum(-1).astype(np.float32)
+
+
+class StageTimer:
+    """Wall-clock split of an entry-point script, like the reference's get_time stamps (optimizer.py:91-266) but per stage
+    of the whole script.  Off unless the environment names a file (HM_STAGE_TIMES=<path.json>): then `lap(name)`
+    synchronises the device, adds the time since the previous lap to `name`, and `write(**extra)` saves the JSON record.
+    Off = no synchronisation, no cost (scripts/e2e_cli_timing.py is the user)."""
+
+    def __init__(self):
+        import os
+        import time
+        self.path = os.environ.get("HM_STAGE_TIMES", "")
+        self.stages = {}
+        self._t = time.perf_counter()
+        self._t0 = self._t
+
+    def lap(self, name):
+        if not self.path:
+            return
+        import time
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        now = time.perf_counter()
+        self.stages[name] = self.stages.get(name, 0.0) + (now - self._t)
+        self._t = now
+
+    def write(self, **extra):
+        if not self.path:
+            return
+        import json
+        import time
+        rec = {"stages_s": {k: round(v, 4) for k, v in self.stages.items()},
+               "total_s": round(time.perf_counter() - self._t0, 4), **extra}
+        with open(self.path, "w") as f:
+            json.dump(rec, f)

@@ -93,8 +93,10 @@ def trained_z_true(params, i):
 
 
 def make_c2_instances(params, dec, ids, kind="joint", device="cuda"):
-    """C2-joint: 1024 surface points + 1 frame x (32 fg + 32 bg) rays; C2-sdf: 2048 surface points, no rays.  A params
-    dict that carries learnt `codes` (a trained decoder) draws its generating latents from them."""
+    """C2-joint: 1024 surface points + 1 frame x (32 fg + 32 bg) rays; C2-sdf: 2048 surface points, no rays; "joint2048":
+    the literal reading of BASELINE.json's "2048 pts/instance" for the JOINT loop -- 2048 surface points plus the same
+    64-ray render block (VERDICT r04 missing #4).  A params dict that carries learnt `codes` (a trained decoder) draws
+    its generating latents from them."""
     Ws, bs = S.fold_weight_norm(params)
     L = int(params["latent_dim"])
     fac = gpu_sdf_factory(dec, device) if (dec is not None and torch.cuda.is_available()) else None
@@ -103,6 +105,8 @@ def make_c2_instances(params, dec, ids, kind="joint", device="cuda"):
         zt = trained_z_true(params, i) if "codes" in params else None
         if kind == "joint":
             d = S.make_instance(Ws, bs, L, i, n_pts=1024, n_frames=1, n_fg=32, n_bg=32, sdf_fn_factory=fac, z_true=zt)
+        elif kind == "joint2048":
+            d = S.make_instance(Ws, bs, L, i, n_pts=2048, n_frames=1, n_fg=32, n_bg=32, sdf_fn_factory=fac, z_true=zt)
         else:
             d = S.make_instance(Ws, bs, L, i, n_pts=2048, n_frames=1, n_fg=4, n_bg=4, sdf_fn_factory=fac, z_true=zt)
         if zt is not None:                       # start from the mean learnt code, as `test_wild_completion.py:46-47` does

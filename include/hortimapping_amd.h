@@ -203,6 +203,21 @@ int hm_workspace_set_host_pacing(hm_workspace_t ws, int on);
  * 0 = automatic (2 groups from 16 instances on; the default), 1 = everything on the caller's stream, up to 4. */
 int hm_workspace_set_groups(hm_workspace_t ws, int groups);
 
+/* Screening of the ray samples under LINEAR occupancy (opt.render.log_sdf_occ = false: lab_pepper.yaml, the challenge
+ * config) in the f16x3 arithmetics.  sdf_to_occupancy (wild_completion/utils.py:125-133) clamps, so a sample beyond
+ * +-occ_cutoff has occupancy exactly 0 / 1 and no gradient (loss.py:66) whatever its exact sdf.  With screening on, every
+ * ball-valid sample first goes through ONE fp16 pass of the decoder; only samples whose fp16 sdf is within
+ * occ_cutoff + eps of zero (or not finite) are decoded by the fp32-class f16x3 forward; samples behind the first
+ * certainly-inside sample of their ray (transmittance exactly 0) are skipped as well.  Results are bit-identical to the
+ * unscreened path as long as eps bounds |sdf_fp16 - sdf_f16x3| (default 1e-3 m: DESIGN.md section 4 has the measurement).
+ *   mode 0 off, 1 on (default; ignored for logistic occupancy and for precisions 0 / 3), 2 on + VERIFY: the exact forward
+ *   also runs over every sample and each screened-far decision is checked against it (tests); eps <= 0 = default.
+ * hm_workspace_screening_stats (after enabling hm_workspace_counters, or in mode 2): out4 = {ball-valid samples of valid
+ * frames screened, promoted to the exact forward, violations found by mode 2 (must be 0), samples skipped behind a
+ * certainly-inside one}; synchronises `stream`; reset != 0 zeroes the sums afterwards (out4 may be NULL). */
+int hm_workspace_set_screening(hm_workspace_t ws, int mode, float eps);
+int hm_workspace_screening_stats(hm_workspace_t ws, int reset, long long* out4, void* stream);
+
 /* Replaces one call of compute_render_loss per frame (wild_completion/loss.py:8-217) for a batch: runs the render
  * front end + Jacobian pass for the current (latent, T_ow) and leaves, per instance, V[b] depth rows followed (at row
  * offset max_frames*max_rays) by V[b] mask rows of L+8 floats [d res/d z | d res/d pose | res] in d_rows

@@ -28,6 +28,13 @@ import torch
 N_LIN = 9
 SKIP_LAYER = 4
 
+# ONE-THING-CHANGED variants of the arithmetic (round 5, scripts/attribute_rank_bias.py: which rounding-level difference
+# between the HIP pipeline and this oracle explains the GPU's rank tilt in the 200-iteration gates).  Empty = the pinned
+# restatement.  Names: "chol32" (fp32 Cholesky solve instead of torch.inverse), "neq64" (normal equations accumulated in
+# fp64, rounded once), "neq_tile64" (fp32 accumulation over 64-row tiles in sequence, the K4 order), "jac64" (sdf and
+# Jacobians evaluated in fp64, rounded once), "linspace_naive" (start + j * step).  `solve64` is a keyword of the loops.
+VARIANT = set()
+
 
 # --------------------------------------------------------------------------------------
 # decoder  (deepsdf/networks/deep_sdf_decoder.py:10-110)
@@ -86,6 +93,13 @@ def decoder_forward(dec: FoldedDecoder, z, x):
 def decoder_jacobian(dec: FoldedDecoder, z, x):
     """(y (n,), g (n, L+3)) with g = d y / d [z ; x] -- get_batch_sdf_jacobian (utils.py:175-193),
     restated without autograd (SURVEY.md 8a 'a1/a3 restated')."""
+    if "jac64" in VARIANT and dec.dtype == torch.float32:
+        VARIANT.discard("jac64")
+        try:
+            y64, g64 = decoder_jacobian(dec.to(torch.float64), z.double(), x.double())
+        finally:
+            VARIANT.add("jac64")
+        return y64.float(), g64.float()
     u = _inputs(dec, z, x)
     h = u
     masks = []
@@ -315,6 +329,18 @@ def default_opt_cfg():
 def _normal_eq(J, r, rho, weight, count, faithful):
     """H_t = w * sum_i rho_i J_i^T J_i / n ; b_t = -w * sum_i rho_i J_i^T r_i / n
     (optimizer.py:152-159,189-190).  `faithful` materialises the (n,E,E) tensor like the reference."""
+    if "neq64" in VARIANT:
+        Jd, rd_, wd = J.double(), r.double(), rho.double()
+        return ((weight * (Jd.T @ (wd[:, None] * Jd)) / count).to(J.dtype),
+                (-weight * (Jd.T @ (wd * rd_)) / count).to(J.dtype))
+    if "neq_tile64" in VARIANT:
+        E = J.shape[1]
+        Hs, bs_ = torch.zeros(E, E, dtype=J.dtype), torch.zeros(E, dtype=J.dtype)
+        for a in range(0, J.shape[0], 64):
+            Jc, wc, rc = J[a:a + 64], rho[a:a + 64], r[a:a + 64]
+            Hs = Hs + Jc.T @ (wc[:, None] * Jc)
+            bs_ = bs_ + Jc.T @ (wc * rc)
+        return weight * Hs / count, -weight * bs_ / count
     if faithful:
         Jb = J[:, None, :]
         H = weight * (rho[:, None, None] * torch.bmm(Jb.transpose(1, 2), Jb)).sum(0) / count
@@ -349,6 +375,8 @@ def render_term(dec, latent, T_ow, render_data, frame_ind, cube_radius, cur_scal
         d_min = T_co[2, 3] - 1.0 * depth_range                              # :110
         d_max = T_co[2, 3] + 0.8 * depth_range
         sd = torch.linspace(float(d_min), float(d_max), M, dtype=dt)        # :111
+        if "linspace_naive" in VARIANT:
+            sd = d_min + (d_max - d_min) / (M - 1) * torch.arange(M, dtype=dt)
         rays = torch.cat([render_data["rays_fg"][idx], render_data["rays_bg"][idx]], 0)   # :113
         out = compute_render_loss(dec, latent, rays, render_data["depth_fg"][idx],
                                   render_data["depth_bg"][idx], T_oc, sd, scale_on,
@@ -434,6 +462,8 @@ def shape_pose_joint_opt(dec: FoldedDecoder, opt_cfg, latent, T_ow, render_data,
         b[P:] += -w_code * latent                                                          # :202-203
         if solve64:
             delta = torch.linalg.solve(H.double(), b.double()).to(dt)
+        elif "chol32" in VARIANT:
+            delta = torch.cholesky_solve(b[:, None], torch.linalg.cholesky(H))[:, 0]
         else:
             delta = torch.mv(torch.inverse(H), b)                                          # :234
         if trace is not None:

@@ -1,0 +1,167 @@
+#!/usr/bin/env python3
+"""the HIP results of the C2-joint free-pose gate sit on the HIGH side of the band spanned by the
+16 one-ulp-perturbed oracle runs (mean rank 0.6-0.7, scale error p = 0.004), in f16x3 AND in exact f32.  Which
+deterministic difference between the HIP pipeline and the oracle causes it?
+
+Step 1 (CPU, hours of core time, resumable):   python scripts/attribute_rank_bias.py run [variant ...]
+    re-runs the NOMINAL inputs of tests/golden/c2_fullsize_inputs.npz (64 instances x {known, free}, 200 iterations) through
+    oracle variants that change ONE thing each (oracle/hm_oracle.py: VARIANT / solve64) -> /tmp/rank_bias/<variant>.npz
+Step 2 (CPU):                                  python scripts/attribute_rank_bias.py collect  -> profiles/r05_rank_bias_variants.npz
+Step 3 (GPU box):                              python scripts/attribute_rank_bias.py table gpurun_out/r05_rank_bias_table.txt
+    optimises the 64 instances on the HIP path and, for every candidate C in {GPU f32, GPU f16x3, each oracle variant} and
+    every reference point R in {oracle nominal, each variant}, prints the statistics of tests/parity_stats.py for
+    |m_C - m_R| against the perturbation band |m_pert - m_nominal| of the committed records -- mean rank, KS p,
+    exchangeability z -- per metric (metrics by the gate's own code, tests/test_gpu_fullsize.py).  If the GPU's tilt vanishes against variant V
+    (mean rank -> 0.5), V names the cause; if EVERY variant is itself tilted against the nominal oracle the way the GPU is,
+    the cause is not one operation but the band: a 1e-7 input change is a smaller disturbance than ANY fp32 re-ordering.
+"""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+SCRATCH = "/tmp/rank_bias"
+VARIANTS = ("solve64", "chol32", "neq64", "neq_tile64", "jac64", "linspace_naive")
+MODES = ("known", "free")
+L = 256
+
+
+def _params():
+    from hortimapping_amd import synthetic as S
+    return S.make_synthetic_decoder(L, seed=2, r0=0.04, aniso=(1.0, 0.75, 1.3))
+
+
+_OD = None
+
+
+def _run(task):
+    variant, mode, i = task
+    out = os.path.join(SCRATCH, f"{variant}_{mode}_{i:03d}.npz")
+    if os.path.exists(out):
+        return out
+    import torch
+    torch.set_num_threads(1)
+    from hortimapping_amd import workloads as W
+    from oracle import hm_oracle as O
+    global _OD
+    if _OD is None:
+        _OD = O.fold_decoder(_params())
+    inp = np.load(os.path.join(ROOT, "tests", "golden", "c2_fullsize_inputs.npz"))
+    d = W.fixture_dicts({k: inp[k][i:i + 1] for k in inp.files})[0]
+    cfg = W.c2_opt_cfg(max_iter=200)
+    rd = {k: [torch.from_numpy(np.ascontiguousarray(a)) for a in v] for k, v in d["render"].items()}
+    O.VARIANT.clear()
+    if variant not in ("solve64", "nominal"):
+        O.VARIANT.add(variant)
+    t = time.time()
+    z, T, n = O.shape_pose_joint_opt(_OD, cfg, torch.from_numpy(d["latent0"]), torch.from_numpy(d["T_ow0"]), rd,
+                                     torch.from_numpy(d["points_w"]), d["cube_radius"], pose_known=(mode == "known"),
+                                     solve64=(variant == "solve64"))
+    O.VARIANT.clear()
+    np.savez(out + ".tmp.npz", latent=z.numpy(), T_ow=T.numpy(), iter_count=n, seconds=time.time() - t)
+    os.replace(out + ".tmp.npz", out)
+    return out
+
+
+def run(variants):
+    import multiprocessing as mp
+    os.makedirs(SCRATCH, exist_ok=True)
+    tasks = [(v, m, i) for v in variants for m in MODES for i in range(64)]
+    t0 = time.time()
+    with mp.get_context("spawn").Pool(min(int(os.environ.get("HM_PROCS", "8")), os.cpu_count())) as pool:
+        for k, _ in enumerate(pool.imap_unordered(_run, tasks)):
+            if k % 32 == 0:
+                print(f"{k + 1}/{len(tasks)} runs, {time.time() - t0:.0f} s", flush=True)
+    for v in variants:
+        rec = {}
+        for m in MODES:
+            rs = [np.load(os.path.join(SCRATCH, f"{v}_{m}_{i:03d}.npz")) for i in range(64)]
+            rec[m + "_latent"] = np.stack([r["latent"] for r in rs])
+            rec[m + "_T_ow"] = np.stack([r["T_ow"] for r in rs])
+        np.savez_compressed(os.path.join(SCRATCH, v + ".npz"), **rec)
+        print("wrote", os.path.join(SCRATCH, v + ".npz"))
+
+
+def collect():
+    """/tmp/rank_bias/<variant>.npz -> profiles/r05_rank_bias_variants.npz (committed: the GPU box has no /tmp of ours)."""
+    rec = {}
+    for v in VARIANTS:
+        f = os.path.join(SCRATCH, v + ".npz")
+        if os.path.exists(f):
+            r = np.load(f)
+            for k in r.files:
+                rec[f"{v}.{k}"] = r[k]
+    out = os.path.join(ROOT, "profiles", "r05_rank_bias_variants.npz")
+    np.savez_compressed(out, **rec)
+    print("wrote", out, sorted({k.split(".")[0] for k in rec}))
+
+
+def table(out_path=None):
+    """GPU box: optimise the 64 instances on the HIP path (f32, f16x3), compute every party's metrics with the gate's own
+    metric code (tests/test_gpu_fullsize.py: exact-f32 GPU sampler) and print the statistics."""
+    import torch
+    import parity_stats as PS
+    import test_gpu_fullsize as TF
+    from hortimapping_amd import optimizer as HO, workloads as W
+    from hortimapping_amd.decoder import DecoderWeights
+    fs = TF.fullsize_fixture("analytic")
+    var = np.load(os.path.join(ROOT, "profiles", "r05_rank_bias_variants.npz"))
+    vnames = sorted({k.split(".")[0] for k in var.files})
+    names = ("chamfer", "t_err", "r_err", "scale")
+    lines = []
+
+    def emit(sx):
+        print(sx, flush=True)
+        lines.append(sx)
+    cfg = W.c2_opt_cfg(max_iter=200)
+    for mode in MODES:
+        emit(f"\n===== C2-joint, 64 instances x 200 iterations, pose mode: {mode} =====")
+        m_all = fs["oracle"][mode]                         # (17, n, 4): nominal + 16 perturbed oracle runs
+        nominal = m_all[0]
+        band = np.abs(m_all[1:] - nominal[None])           # (16, n, 4)
+        cands = {}
+        for prec in ("f32", "f16x3"):
+            dec = DecoderWeights.from_params(fs["params"]).set_precision(prec)
+            res = HO.optimize_batch(dec, cfg, TF.fullsize_instances(mode == "known"))
+            cands["GPU " + prec] = fs["metrics"](np.stack([r.latent.numpy() for r in res]),
+                                                 np.stack([r.T_ow.numpy() for r in res]))
+        for v in vnames:
+            cands["oracle " + v] = fs["metrics"](var[f"{v}.{mode}_latent"], var[f"{v}.{mode}_T_ow"])
+        scale = np.stack([nominal[:, 0], np.maximum(nominal[:, 1], 1e-3), np.maximum(nominal[:, 2], 0.1), np.ones(fs["n"])], axis=1)
+        floor = TF.REL_FLOOR * scale
+        refs = {"oracle nominal": nominal, **{k: v for k, v in cands.items() if k.startswith("oracle ")}}
+        emit("candidate              vs reference point        | per metric: outright-1e-4 count, mean rank of the rest (0.5 = one more "
+             "perturbed run), KS p, exchangeability z over all 64")
+        for cname, cm in cands.items():
+            for rname, rm in refs.items():
+                if rname == cname or not (rname == "oracle nominal" or cname.startswith("GPU")):
+                    continue
+                cells = []
+                for j, nm in enumerate(names):
+                    dev = np.abs(cm[:, j] - rm[:, j])
+                    gt = PS.gate(dev, band[:, :, j], floor[:, j])
+                    ex = PS.exchange_test(dev, band[:, :, j])
+                    cells.append(f"{nm}: {gt['outright']:2d} rank {gt['mean_rank']:.2f} p {gt['p']:.3f} z {ex['z']:+.1f}")
+                emit(f"{cname:22s} vs {rname:22s} | " + " | ".join(cells))
+        # how large is each party's deviation from the nominal oracle, in units of the instance's own band (median over instances)
+        emit("median over instances of |m - m_nominal| / (largest of the 16 perturbed deviations):")
+        for cname, cm in cands.items():
+            ratio = np.abs(cm - nominal) / np.maximum(band.max(axis=0), 1e-300)
+            emit(f"  {cname:22s} " + "  ".join(f"{nm} {np.median(ratio[:, j]):.2f}" for j, nm in enumerate(names)))
+    if out_path:
+        open(out_path, "w").write("\n".join(lines) + "\n")
+
+
+if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "run":
+        run(sys.argv[2:] or list(VARIANTS))
+    elif len(sys.argv) > 1 and sys.argv[1] == "collect":
+        collect()
+    elif len(sys.argv) > 1 and sys.argv[1] == "table":
+        table(sys.argv[2] if len(sys.argv) > 2 else None)
+    else:
+        print(__doc__)

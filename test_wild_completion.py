@@ -28,6 +28,7 @@ from hortimapping_amd import data_prep as DP, datasets as DS, synthetic as S
 from hortimapping_amd.decoder import DecoderWeights, config_decoder, load_latent_vectors
 from hortimapping_amd.mesher import MeshExtractor, read_ply, write_ply
 from hortimapping_amd.optimizer import Instance, Optimizer, STATUS_INVALID
+from hortimapping_amd.utils import StageTimer
 
 
 def load_decoder(cfg):
@@ -51,6 +52,7 @@ def load_decoder(cfg):
 def main(config, dump_jobs):
     np.random.seed(42)                                                  # set_random_seed(42), utils.py:638-641
     torch.manual_seed(42)
+    timer = StageTimer()                                                # off unless HM_STAGE_TIMES names a file
     cfg = yaml.safe_load(open(config))
     dtype = torch.float32
     decoder, init_latent, _ = load_decoder(cfg)
@@ -76,6 +78,7 @@ def main(config, dump_jobs):
         # is rerun in exact fp32 by the Optimizer itself (hortimapping_amd/optimizer.py: retry_f32)
         decoder.set_precision("f16x3")
     opt = Optimizer(cfg, decoder, mesh_extractor, None)
+    timer.lap("load decoder + frames")
 
     # instance loop of the reference (:133), split in two so that the image scans of get_render_data run on the GPU for
     # all instances at once; the np.random.choice draws inside keep the reference's order (submap by submap)
@@ -90,6 +93,7 @@ def main(config, dump_jobs):
             bg_at[len(entries)] = DP.voxel_down_sample(cur_mesh.sample_points_uniformly(500000, seed=42), 0.005)
             continue
         entries.append((submap_name, submap_id, cur_mesh))
+    timer.lap("read submap meshes (+ background cloud)")
     dev_frames = DP.DeviceFrames(frames["id"], frames["depth"])
     render_all = DP.get_render_data_device([e[1] for e in entries], dev_frames, frames["pose"], img_size, invK, cfg)
 
@@ -130,28 +134,40 @@ def main(config, dump_jobs):
         inst = Instance(init_latent.clone(), torch.tensor(inv(T_wo), dtype=dtype), torch.tensor(pts, dtype=dtype),
                         render_all[k], object_radius_max_m, False)
         jobs.append((submap_name, submap_id, pts, inst))
+    timer.lap("device data prep (render data, DBSCAN, pose init)")
     print("Optimising %d fruit instances in one batch" % len(jobs))
     results = opt.optimize_batch([j[3] for j in jobs]) if jobs else []
+    timer.lap("optimise (pack + upload + LM loop + download)")
     if dump_jobs:                     # tests/test_gpu_cli.py feeds exactly these inputs to the CPU oracle
         DS.dump_jobs(dump_jobs, [(j[0], j[3]) for j in jobs], results, cfg["opt"], opt.decoder.precision)
 
     kept = 0
+    checks = []
     for (submap_name, submap_id, pts, _), res in zip(jobs, results):
         if res.status & STATUS_INVALID:
             print("Submap %d: not valid (no depth residuals)" % submap_id)
-        out = cfg["opt"]["outlier"]
-        T_wo, final_scale, (yaw, pitch, roll), keep = DP.final_pose_check(res.T_ow.numpy().astype(np.float64), out)
+        checks.append(DP.final_pose_check(res.T_ow.numpy().astype(np.float64), cfg["opt"]["outlier"]))
+    # the completed meshes of ALL kept fruits: one batched grid decode + one marching-cubes launch (the reference meshes
+    # fruit by fruit inside its loop, :249; same meshes either way)
+    keep_idx = [k for k, c in enumerate(checks) if c[3]]
+    meshes = dict(zip(keep_idx, mesh_extractor.extract_meshes(torch.stack([results[k].latent for k in keep_idx])))) if keep_idx else {}
+    timer.lap("grid decode + marching cubes (all kept fruits, batched)")
+    for k, ((submap_name, submap_id, pts, _), res) in enumerate(zip(jobs, results)):
+        T_wo, final_scale, (yaw, pitch, roll), keep = checks[k]
         if not keep:                                                              # :238-246
             print("Submap %d: final scale %f / pitch %f / roll %f is an outlier, not valid"
                   % (submap_id, final_scale, pitch, roll))
             continue
-        mesh = mesh_extractor.complete_mesh(res.latent, T_wo, None)
+        mesh = meshes[k].transform(T_wo)                                          # complete_mesh, mesher.py:26-32
         write_ply(mesh, os.path.join(complete_submap_folder, submap_name))       # :249-252
         DS.write_points_ply(pts, os.path.join(clean_submap_folder, submap_name))  # :254-256
         np.save(os.path.join(pose_folder, submap_name.replace("ply", "npy")), T_wo)   # :258-260
         kept += 1
         print("Submap %d: %d iterations, scale %.3f -> %s" % (submap_id, res.iter_count, final_scale,
                                                               os.path.join(complete_submap_folder, submap_name)))
+    timer.lap("weld check + write .ply / .npy")
+    timer.write(script="test_wild_completion.py", fruits=len(jobs), kept=kept,
+                mean_iterations=float(np.mean([r.iter_count for r in results])) if results else 0.0)
     print("Completed %d of %d submaps" % (kept, len(jobs)))
 
 

@@ -236,6 +236,11 @@ def test_trajectories_vs_golden(name):
     assert abs(res.iter_count - int(g["iter_count"])) <= T(K_NOISE * nit, max(K_NOISE * nit, 2))
     assert res.status == _STATUS.get(tag, 8), res.status
     tz, tT = max(T(1e-3, 3e-2), K_NOISE * nz), max(T(1e-4, 3e-3), K_NOISE * nT)
+    if tag.startswith("invalid_norays_later"):
+        # one or two emitted rays at iteration 0 and a free pose that diverges until no ray is left: the reference moves by
+        # 0.4 % (latent) / 2.6 % (pose) under a 1e-7 input change.  The fp32-class arithmetics stay inside 3 x that; the mixed
+        # mode (Jacobians ~1e-3, reported, not fp32-class) is only required to take the same exit at the same iteration.
+        tz, tT = T(tz, float("inf")), T(tT, float("inf"))
     if np.abs(g["z_out"]).max() > 0:
         assert relmax(res.latent, g["z_out"]) < tz
     else:
