@@ -196,11 +196,13 @@ def shipped_config_bench(name, precision, steps=3, warmup=1):
     dt = (time.perf_counter() - t0) / steps
     for g in groups:
         lib.hm_workspace_counters(g["ws"].handle, 1)
+        g["ws"].screening_stats(reset=True)
     step()
     A, cnts, its = 0.0, [], []
     for g in groups:
         out5 = (ctypes.c_longlong * 5)()
         lib.hm_workspace_counters_read(g["ws"].handle, out5, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+        scr = g["ws"].screening_stats(reset=True)     # linear-occupancy screening (zeros where it does not apply)
         lib.hm_workspace_counters(g["ws"].handle, 0)
         n_ii, n_s_q, n_f, n_g, n_v = [int(v) for v in out5]
         E = g["E"]
@@ -215,7 +217,14 @@ def shipped_config_bench(name, precision, steps=3, warmup=1):
                      "max_iter": int(g["opt"]["converge"]["max_iter"]),
                      "iterations": {"mean": round(float(it.mean()), 2), "min": int(it.min()), "max": int(it.max())},
                      "counts_per_step": {"instance_iterations": n_ii, "N_J_sdf_term": n_s_q, "N_J_render": n_g,
-                                         "N_F_ray_samples": n_f, "V_rays": n_v}})
+                                         "N_F_ray_samples": n_f, "V_rays": n_v},
+                     "screening": ({"applies": True, "one_pass_fp16_screened": scr["screened"],
+                                    "promoted_to_f16x3_forward": scr["promoted"], "skipped_behind_an_inside_sample": scr["dead"],
+                                    "promoted_fraction": round(scr["promoted"] / max(1, scr["screened"]), 4),
+                                    "note": "linear occupancy: samples beyond occ_cutoff + 1 mm take occupancy exactly 0 / 1 "
+                                            "(utils.py:125-133); bit-identical results (tests/test_gpu_round5.py); the roofline "
+                                            "below still prices the DENSE algorithmic flop"}
+                                   if scr["screened"] > 0 else {"applies": False})})
     n = sum(int(g["pb"].B) for g in groups)
     peak = PRECISIONS[precision][0]
     ach = A / dt / 1e12
@@ -227,7 +236,7 @@ def shipped_config_bench(name, precision, steps=3, warmup=1):
             "roofline_step": {"algorithmic_flop_per_step": int(A), "achieved": round(ach, 2), "peak": peak,
                               "unit": "TFLOP/s", "frac": round(ach / peak, 4), "ms_per_step": round(dt * 1e3, 3)},
             "data": "synthetic fruits (%d distinct per group, replicated), analytic L = 32 decoder" % SHIPPED_DISTINCT,
-            "profile": "profiles/r04_%s_kernel_stats.txt (rocprofv3 --kernel-trace --stats of `bench.py --shipped-only %s`)" % (name, name)}
+            "profile": "profiles/r05_%s_kernel_stats.txt (rocprofv3 --kernel-trace --stats of `bench.py --shipped-only %s`)" % (name, name)}
 
 
 def parse_args(argv=None):

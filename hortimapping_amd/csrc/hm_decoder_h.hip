@@ -168,8 +168,16 @@ __device__ __forceinline__ void step_h(f32x16 (&acc)[2][2], const ASet& a, const
   const f16x8* ph = xh + kb * 2 * TQ + xo;
   const f16x8* pl = xl + kb * 2 * TQ + xo;
   if (U0 && U1) {
+#if defined(HM_EXPERIMENTAL) && defined(HM_ABL_NOSCALE)      // round 5 timing ablation: no v_pk_mul_f16 at all (wrong results)
+    const f16x8 a0c = a.h0;
+    const f16x8 a1c = a.h1;
+#elif defined(HM_EXPERIMENTAL) && defined(HM_ABL_HALFSCALE)  // only the second row block's weight operand is rescaled
+    const f16x8 a0c = a.h0;
+    const f16x8 a1c = a.h1 * cs;
+#else
     const f16x8 a0c = a.h0 * cs;
     const f16x8 a1c = a.h1 * cs;
+#endif
     HM_FENCE();
     HM_MFMA(a.h0, b.h0, acc[0][0]); HM_MFMA(a.h0, b.h1, acc[0][1]);
     HM_FENCE(); HM_LDB(bn.h0, ph[0]); HM_LDB(bn.h1, ph[32]); HM_FENCE();

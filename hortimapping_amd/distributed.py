@@ -20,7 +20,21 @@ import torch.distributed as dist
 # variable is read when the HSA runtime starts, so it is set here, at import, before any rank touches the GPU -- for every
 # launch path alike (torch.distributed.run started by the driver, bench.py's own spawn, a user's script).  A value the
 # caller exported wins.
-os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+def _set_ipc_mode():
+    """setdefault + a warning when it comes too late: the HSA runtime reads the variable when it starts, so a process that
+    has already initialised the GPU (torch.cuda touched before this import) keeps whatever mode it started with."""
+    if "HSA_ENABLE_IPC_MODE_LEGACY" in os.environ:
+        return
+    os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    if torch.cuda.is_available() and torch.cuda.is_initialized():
+        import warnings
+        warnings.warn("hortimapping_amd.distributed was imported after the GPU runtime started: HSA_ENABLE_IPC_MODE_LEGACY=0 "
+                      "could not take effect in this process; multi-process RCCL may fail with 'hipIpcGetMemHandle: invalid "
+                      "argument'.  Export HSA_ENABLE_IPC_MODE_LEGACY=0 before starting Python (or import hortimapping_amd "
+                      "before touching torch.cuda).", RuntimeWarning, stacklevel=3)
+
+
+_set_ipc_mode()
 
 
 def shard_bounds(n: int, rank: int, world: int) -> Tuple[int, int]:

@@ -496,7 +496,7 @@ def shape_pose_joint_opt(dec: FoldedDecoder, opt_cfg, latent, T_ow, render_data,
 
 
 def shape_opt_deepsdf(dec: FoldedDecoder, opt_cfg, latent, T_ow, points_w, faithful=False,
-                      trace: Optional[list] = None, solve64=False):
+                      trace: Optional[list] = None, solve64=False, exit_info: Optional[dict] = None):
     """Optimizer.shape_opt_deepsdf (optimizer.py:306-429): SDF term + code regulariser, pose frozen."""
     o = opt_cfg
     dt = dec.dtype
@@ -513,6 +513,7 @@ def shape_opt_deepsdf(dec: FoldedDecoder, opt_cfg, latent, T_ow, points_w, faith
     L = latent.shape[0]
     points_w = points_w.to(dt)
     iter_count = 0
+    reason = "max_iter"
     for i in range(max_iter):                                               # :337
         pts_o = (points_w[..., None, :] * T_ow[:3, :3]).sum(-1) + T_ow[:3, 3]   # :343
         r_s, _, Jc = compute_sdf_loss(dec, latent, pts_o, scale_on)             # :345
@@ -534,9 +535,13 @@ def shape_opt_deepsdf(dec: FoldedDecoder, opt_cfg, latent, T_ow, points_w, faith
         latent = latent + delta                                                 # :401
         iter_count = i + 1                                                      # :414
         if bool(torch.max(torch.abs(b)) < eps_g) and i > 1:                     # :417
+            reason = "grad"
             break
         if bool(torch.max(torch.abs(delta / (latent + 1e-12))) < eps_c) and i > 1:   # :421
+            reason = "code"
             break
+    if exit_info is not None:
+        exit_info["reason"] = reason
     return latent, T_ow, iter_count
 
 

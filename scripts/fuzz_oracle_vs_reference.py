@@ -197,6 +197,69 @@ def run_oracle(p, cfg, inst, pose_known):
     return z.numpy(), T.numpy(), int(n), info["reason"], tr
 
 
+def check_case_sdf(ns, seed, tol=1e-5):
+    """The shape-only loop (Optimizer.shape_opt_deepsdf, optimizer.py:306-429) on the same kind of random case: surface
+    points only, pose frozen; iter_count, exit branch, first H / b and the final latent."""
+    c = draw_case(seed)
+    p, inst, cfg = build_case(c)
+    rdec = ref_shim.build_reference_decoder(ns, p)
+    rs = np.random.RandomState(777 + seed)
+    z0 = (0.03 * rs.randn(c["L"])).astype(np.float32) if seed % 2 else inst["latent0"].copy()
+    opt = ns.optimizer.Optimizer(copy.deepcopy(cfg), rdec, None, None)
+    cap = {}
+    real_inv, real_mv = torch.inverse, torch.mv
+
+    def cap_inverse(A):
+        if A.shape[0] > 4 and "H" not in cap:
+            cap["H"] = A.clone()
+        return real_inv(A)
+
+    def cap_mv(A, v):
+        if A.shape[0] > 4 and "b" not in cap:
+            cap["b"] = v.clone()
+        return real_mv(A, v)
+    torch.inverse, torch.mv = cap_inverse, cap_mv
+    buf = io.StringIO()
+    try:
+        with contextlib.redirect_stdout(buf):
+            zr, _, nr = opt.shape_opt_deepsdf(t(z0.copy()), t(inst["T_ow0"].copy()), t(inst["points_w"]), None)
+    finally:
+        torch.inverse, torch.mv = real_inv, real_mv
+    reason_r = "max_iter"
+    for needle, name in REASONS:
+        if needle in buf.getvalue():
+            reason_r = name
+            break
+    tr, info = [], {}
+    zo, _, no = O.shape_opt_deepsdf(O.fold_decoder(p), cfg["opt"], t(z0.copy()), t(inst["T_ow0"].copy()), t(inst["points_w"]),
+                                    faithful=True, trace=tr, exit_info=info)
+    rec = {"seed": seed, "iter": (int(nr), int(no)), "reason": (reason_r, info["reason"]), "rows": [], "V": [], "noise": None,
+           "eH": rel(tr[0].H.numpy(), cap["H"].numpy(), 1e-30), "eb": rel(tr[0].b.numpy(), cap["b"].numpy(), 1e-30),
+           "ez": rel(zo.numpy(), zr.numpy(), 1e-3), "eT": 0.0, "case": c}
+    fails = []
+    if nr != no:
+        fails.append("iter_count")
+    if reason_r != info["reason"]:
+        fails.append("exit reason")
+    if rec["eH"] > tol:
+        fails.append("H")
+    if rec["eb"] > tol:
+        fails.append("b")
+    if rec["ez"] > tol and not fails:
+        nz = 0.0
+        for eps in (1e-7, -1e-7, 1e-6, -1e-6):
+            o2 = ns.optimizer.Optimizer(copy.deepcopy(cfg), rdec, None, None)
+            with contextlib.redirect_stdout(io.StringIO()):
+                z2, _, _ = o2.shape_opt_deepsdf(t(z0.copy()), t(inst["T_ow0"].copy()),
+                                                t((inst["points_w"] * np.float32(1 + eps)).astype(np.float32)), None)
+            nz = max(nz, rel(z2.numpy(), zr.numpy(), 1e-3))
+        rec["noise"] = (nz, 0.0)
+        if rec["ez"] > max(tol, 3 * nz):
+            fails.append("state")
+    rec["fails"] = fails
+    return not fails, rec
+
+
 def rel(a, b, floor):
     return float(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64)).max() / max(float(np.abs(b).max()), floor))
 
@@ -247,12 +310,13 @@ def main():
     ap.add_argument("--cases", type=int, default=240)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--out", default=None)
+    ap.add_argument("--kind", default="joint", choices=["joint", "sdf"], help="sdf: the shape-only loop (shape_opt_deepsdf)")
     a = ap.parse_args()
     ns = ref_shim.import_reference()
     lines, bad, noisy = [], [], 0
     hist = {}
     for s in range(a.seed, a.seed + a.cases):
-        ok, r = check_case(ns, s)
+        ok, r = check_case(ns, s) if a.kind == "joint" else check_case_sdf(ns, s)
         hist[r["reason"][0]] = hist.get(r["reason"][0], 0) + 1
         c = r["case"]
         line = (f"seed {s:4d} L{c['L']} {'sim3' if c['scale_on'] else 'se3 '} {'log' if c['log_occ'] else 'lin'} "
