@@ -134,8 +134,9 @@ def table(out_path=None):
         scale = np.stack([nominal[:, 0], np.maximum(nominal[:, 1], 1e-3), np.maximum(nominal[:, 2], 0.1), np.ones(fs["n"])], axis=1)
         floor = TF.REL_FLOOR * scale
         refs = {"oracle nominal": nominal, **{k: v for k, v in cands.items() if k.startswith("oracle ")}}
-        emit("candidate              vs reference point        | per metric: outright-1e-4 count, mean rank of the rest (0.5 = one more "
-             "perturbed run), KS p, exchangeability z over all 64")
+        emit("candidate              vs reference point        | per metric: outright-1e-4 count | ranks over the instances whose CANDIDATE "
+             "deviation exceeds the floor (the rounds 3-4 gate): n, mean rank (0.5 = one more perturbed run), KS p | ranks over the "
+             "instances where the largest of all 17 deviations exceeds it (symmetric selection, round 5) | exchangeability z over all 64")
         for cname, cm in cands.items():
             for rname, rm in refs.items():
                 if rname == cname or not (rname == "oracle nominal" or cname.startswith("GPU")):
@@ -143,9 +144,11 @@ def table(out_path=None):
                 cells = []
                 for j, nm in enumerate(names):
                     dev = np.abs(cm[:, j] - rm[:, j])
-                    gt = PS.gate(dev, band[:, :, j], floor[:, j])
+                    gc = PS.gate(dev, band[:, :, j], floor[:, j], selection="candidate")      # rounds 3-4
+                    gs = PS.gate(dev, band[:, :, j], floor[:, j], selection="symmetric")      # round 5
                     ex = PS.exchange_test(dev, band[:, :, j])
-                    cells.append(f"{nm}: {gt['outright']:2d} rank {gt['mean_rank']:.2f} p {gt['p']:.3f} z {ex['z']:+.1f}")
+                    cells.append(f"{nm}: {gc['outright']:2d} | cand-sel n {gc['ranked']:2d} rank {gc['mean_rank']:.2f} p {gc['p']:.3f} | "
+                                 f"sym-sel n {gs['ranked']:2d} rank {gs['mean_rank']:.2f} p {gs['p']:.3f} | z {ex['z']:+.1f}")
                 emit(f"{cname:22s} vs {rname:22s} | " + " | ".join(cells))
         # how large is each party's deviation from the nominal oracle, in units of the instance's own band (median over instances)
         emit("median over instances of |m - m_nominal| / (largest of the 16 perturbed deviations):")

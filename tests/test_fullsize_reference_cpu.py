@@ -151,6 +151,33 @@ def test_rank_statistics_helper():
     assert g3["ok"] and g3["outright"] == 400 and g3["ranked"] == 0
 
 
+def test_candidate_side_selection_biases_the_rank_gate_and_symmetric_selection_does_not():
+    """Round 5.  Exchangeable synthetic data -- candidate and 16 stand-ins drawn from ONE law per
+    instance -- with a floor that removes about two thirds of the instances, as the 1e-4 floor does for the scale error of
+    the C2-joint gate.  Ranking only the instances whose CANDIDATE exceeds the floor (rounds 3-4) tilts the mean rank to
+    ~0.7 and rejects a true null far more often than alpha; the symmetric rule (largest of all 17 deviations above the
+    floor) leaves the ranks uniform.  This is the attribution of the GPU's 'high-side rank bias': a property of the gate,
+    shared by every one-operation variant of the oracle itself (profiles/r05_rank_bias_table.txt)."""
+    rs = np.random.RandomState(1)
+    n, K, trials = 64, 16, 400
+    rej = {"candidate": 0, "symmetric": 0}
+    mean_rank = {"candidate": [], "symmetric": []}
+    for _ in range(trials):
+        scale = np.exp(rs.normal(0.0, 1.5, n))                       # instance-to-instance spread of the noise level
+        allv = np.abs(rs.standard_normal((K + 1, n))) * scale
+        floor = np.full(n, np.quantile(allv[0], 0.66))                # ~2/3 of the candidates inside the floor
+        for sel in rej:
+            g = PS.gate(allv[0], allv[1:], floor, alpha=0.01, selection=sel)
+            rej[sel] += (not g["ok"]) and g["has_power"]
+            if g["ranked"]:
+                mean_rank[sel].append(g["mean_rank"])
+    mc, ms = float(np.mean(mean_rank["candidate"])), float(np.mean(mean_rank["symmetric"]))
+    print(f"true null, floor removes 2/3: candidate-side selection mean rank {mc:.2f}, rejected at 1 % in {rej['candidate']} of "
+          f"{trials} trials; symmetric selection mean rank {ms:.2f}, rejected in {rej['symmetric']}")
+    assert mc > 0.62 and rej["candidate"] > 0.10 * trials           # biased: a true null fails >> 1 % of the time
+    assert abs(ms - 0.5) < 0.03 and rej["symmetric"] <= 0.03 * trials
+
+
 def test_wellconditioned_case_oracle_equals_reference():
     """The well-conditioned full-size free-pose case (tests/golden/wc_fullsize_*.npz; workloads.wc_opt_cfg): after 200
     iterations with a FREE pose the oracle and the ACTUAL reference agree to fp32 rounding in state (not merely in

@@ -101,9 +101,16 @@ REL_FLOOR = 1e-4       # BASELINE.json north_star: "Chamfer distance / pose erro
 #   (2) the KS rank gate, asserted where it has power (its smallest attainable p is below alpha) and reported otherwise;
 #   (3) a per-instance cap: no instance beyond K_CAP x its own perturbation band in more than N_CAP_OUT metric entries,
 #       none at all beyond K_GROSS x.
-# alpha = 1e-3 per gate is a family-wise choice: 2 arithmetics x 2 modes x 2 record sets x 4 metrics = 32 gated
-# statistics per layer, so a true-null suite fails about once in 30 runs at 1e-3 and about once in 3 at 1e-2.
-ALPHA = 1e-3
+# Round 5: the KS layer ranked the instances whose CANDIDATE deviation exceeded the floor -- a
+# selection that tilts the surviving ranks towards 1 under a true null (mean rank 0.66 and 29 % rejections at 1 % on
+# exchangeable synthetic data, tests/test_fullsize_reference_cpu.py) and produced the "high-side rank bias" of the scale
+# error (p = 0.004) for the HIP results and for every one-operation variant of the oracle alike
+# (profiles/r05_rank_bias_table.txt).  `parity_stats.gate` now selects symmetrically (largest of all 17 deviations above
+# the floor): the HIP ranks come out at 0.49-0.55 with p >= 0.098 in both fp32-class arithmetics and both pose modes, and
+# the gates are asserted at alpha = 1e-2.  (The statistics are deterministic -- fixed records, bitwise reproducible HIP
+# results -- so alpha is a statement about the margin, not a flake rate: the smallest gated p of this build is 0.045, the
+# reference-record Chamfer gate in pose_known mode; the rejected modes sit below 1e-4.)
+ALPHA = 1e-2
 K_GROSS = 10.0
 K_CAP = 4.0
 N_CAP_OUT = 1
