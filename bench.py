@@ -154,7 +154,7 @@ SHIPPED = {
 SHIPPED_DISTINCT = 16         # distinct synthetic fruits per group, replicated cyclically
 
 
-def shipped_config_bench(name, precision, steps=3, warmup=1):
+def shipped_config_bench(name, precision, steps=3, warmup=1, n_groups=0):
     """One `SHIPPED` configuration on this GPU: every group packed once (inputs resident), `steps` timed optimisations of
     all groups back to back (fresh initial state each step), then one untimed step with the device-side work counters for
     the whole-step algorithmic flop (SURVEY.md 8d formula).  Early exits are ON, as shipped."""
@@ -176,7 +176,7 @@ def shipped_config_bench(name, precision, steps=3, warmup=1):
         insts = [W.to_instance(protos[i % SHIPPED_DISTINCT], pose_known=known) for i in range(n)]
         hcfg = HO.opt_cfg_from_dict(opt)
         pb = HO.PackedBatch(insts, L, int(opt["render"]["n_frame"]), "cuda")
-        ws = HO.Workspace(dec, pb.B, pb.points_stride, pb.F, pb.R, hcfg.n_sample_on_ray)
+        ws = HO.Workspace(dec, pb.B, pb.points_stride, pb.F, pb.R, hcfg.n_sample_on_ray).set_groups(n_groups)
         groups.append(dict(yaml=y, opt=opt, hcfg=hcfg, pb=pb, ws=ws, dec=dec, known=known, shape=shape,
                            init=(pb.latent.clone(), pb.T_ow.clone()), E=L + (7 if opt["scale_on"] else 6)))
 
@@ -304,7 +304,7 @@ def main(argv=None, emit=True):
     args = parse_args(argv)
     if args.shipped_only:
         torch.cuda.set_device(0)
-        o = shipped_config_bench(args.shipped_only, args.precision, max(1, args.steps), args.warmup)
+        o = shipped_config_bench(args.shipped_only, args.precision, max(1, args.steps), args.warmup, args.groups)
         if emit:
             print(json.dumps({args.shipped_only: o}), flush=True)
         return o

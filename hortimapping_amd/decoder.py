@@ -103,22 +103,6 @@ class DecoderWeights:
             self._f32_twin = tw
         return tw
 
-    def f16_twin(self) -> "DecoderWeights":
-        """A second handle on the same weights fixed at the plain-fp16 arithmetic (one MFMA pass, 128-query tiles): the
-        screening decode of `MeshExtractor` (a sign / coarse-magnitude pass; never a result by itself)."""
-        if self.precision == "f16":
-            return self
-        tw = getattr(self, "_f16_twin", None)
-        if tw is None:
-            env = os.environ.pop("HM_PRECISION", None)
-            try:
-                tw = DecoderWeights(self.Ws, self.bs, self.latent_dim).set_precision("f16")
-            finally:
-                if env is not None:
-                    os.environ["HM_PRECISION"] = env
-            self._f16_twin = tw
-        return tw
-
     @classmethod
     def from_params(cls, params):
         """`params`: dict of lin{l}.weight_v/weight_g/bias (+ lin8.weight) arrays plus 'latent_dim'."""

@@ -121,11 +121,8 @@ def weld(soup: np.ndarray):
 class MeshExtractor(object):
     """Drop-in for `wild_completion.mesher.MeshExtractor` (mesher.py:5-32)."""
 
-    SCREEN_EPS = 1.0e-3        # [m] bound on |sdf_fp16 - sdf_f16x3| with 10 x room (profiles/r05_screen_eps.txt: worst 1.04e-4)
-
-    def __init__(self, decoder, code_len=64, voxels_dim=64, cube_radius=1.0, method="mc", screen=True):
+    def __init__(self, decoder, code_len=64, voxels_dim=64, cube_radius=1.0, method="mc"):
         self.method = method
-        self.screen = bool(screen)
         self.decoder = as_weights(decoder)
         self.code_len = code_len
         self.voxels_dim = int(voxels_dim)
@@ -137,60 +134,14 @@ class MeshExtractor(object):
         pts4[:n3, :3] = self.voxel_points
         self._pts4 = pts4.cuda()
 
-    def _screened_decode(self, lat, pts, nq):
-        """Round 5.  Marching cubes only looks at cells whose corners change sign, so only THEIR corners need the fp32-class
-        value.  Pass 1: the whole grid in ONE fp16 pass (K1p, a quarter of the f16x3 cost per query).  A cell is "possibly
-        crossing" when min(corner) - eps <= 0 <= max(corner) + eps (or a corner is not finite), eps bounding the fp16 error:
-        every cell the EXACT values make cross the zero level is then flagged.  Pass 2: the f16x3 forward over the corners of
-        the flagged cells (a shell two cells thick, a few per cent of the grid), written back over the fp16 values.  Unflagged
-        cells have eight corners of one sign in both value sets and emit nothing, so the triangle soup -- vertices included,
-        they interpolate exact corner values -- is bit-identical to the unscreened one (tests/test_gpu_round5.py)."""
-        B, n, n3 = lat.shape[0], self.voxels_dim, self.voxels_dim ** 3
-        y, _ = ops.decode_batch(self.decoder.f16_twin(), lat, pts, nq, mode=0)
-        g = y[:, :n3].reshape(B, n, n, n)
-        fin = torch.isfinite(g)
-        lo = torch.where(fin, g, torch.full_like(g, -1.0))
-        hi = torch.where(fin, g, torch.full_like(g, 1.0))
-        cmin, cmax = lo, hi
-        for d in range(3):                                            # min / max over the 2 x 2 x 2 corners of every cell
-            a, b = cmin.narrow(d + 1, 0, cmin.shape[d + 1] - 1), cmin.narrow(d + 1, 1, cmin.shape[d + 1] - 1)
-            cmin = torch.minimum(a, b)
-            a, b = cmax.narrow(d + 1, 0, cmax.shape[d + 1] - 1), cmax.narrow(d + 1, 1, cmax.shape[d + 1] - 1)
-            cmax = torch.maximum(a, b)
-        cell = (cmin - self.SCREEN_EPS <= 0) & (cmax + self.SCREEN_EPS >= 0)           # (B, n-1, n-1, n-1)
-        prom = torch.zeros(B, n, n, n, dtype=torch.bool, device=g.device)
-        for dx in (0, 1):
-            for dy in (0, 1):
-                for dz in (0, 1):
-                    prom[:, dx:dx + n - 1, dy:dy + n - 1, dz:dz + n - 1] |= cell
-        prom = prom.reshape(B, n3)
-        cnt = prom.sum(dim=1)
-        cmax_n = int(cnt.max())
-        self.last_screening = {"grid_points": B * n3, "promoted": int(cnt.sum())}
-        if cmax_n == 0:
-            return y
-        npad = (cmax_n + 63) // 64 * 64
-        pos = torch.cumsum(prom, dim=1) - 1                          # slot of every promoted corner inside its instance
-        bi, qi = prom.nonzero(as_tuple=True)
-        sub = torch.zeros(B, npad, 4, device=g.device)
-        sub[bi, pos[bi, qi]] = pts[0, qi]                            # every instance decodes the same grid positions
-        ys, _ = ops.decode_batch(self.decoder, lat, sub, cnt.to(torch.int32), mode=0)
-        y[:, :n3][bi, qi] = ys[bi, pos[bi, qi]]
-        return y
-
-    def decode_grids(self, latents: torch.Tensor, screened: bool = False) -> torch.Tensor:
-        """(B, L) latents -> (B, n, n, n) sdf grids, all instances in one forward launch.  `screened` (what `extract_meshes`
-        passes when the decoder runs an fp16-operand arithmetic): only the corners of cells that may cross the zero level
-        carry the decoder's arithmetic, the others one-pass fp16 values of the right sign -- see `_screened_decode`."""
+    def decode_grids(self, latents: torch.Tensor) -> torch.Tensor:
+        """(B, L) latents -> (B, n, n, n) sdf grids, all instances in one forward launch."""
         lat = latents.detach().to("cuda", torch.float32).reshape(-1, self.decoder.latent_dim).contiguous()
         B = lat.shape[0]
         n3 = self.voxels_dim ** 3
         pts = self._pts4[None].expand(B, -1, -1).contiguous()
         nq = torch.full((B,), n3, dtype=torch.int32, device="cuda")
-        if screened and self.decoder.precision in ("f16x3", "f16x3f_f16b"):
-            y = self._screened_decode(lat, pts, nq)
-        else:
-            y, _ = ops.decode_batch(self.decoder, lat, pts, nq, mode=0)
+        y, _ = ops.decode_batch(self.decoder, lat, pts, nq, mode=0)
         if self.decoder.precision != "f32":
             # The fp16-operand arithmetics poison a 64-query tile whose activations leave the fp16 range (NaN sdf, never
             # silent garbage).  The optimiser retries such instances in exact fp32; the grid decode does the same here, per
@@ -205,7 +156,7 @@ class MeshExtractor(object):
         return y[:, :n3].reshape(B, n, n, n)
 
     def extract_meshes(self, latents: torch.Tensor) -> List[TriangleMesh]:
-        soups = extract_surface(self.decode_grids(latents, screened=self.screen), self.cube_radius, method=self.method)
+        soups = extract_surface(self.decode_grids(latents), self.cube_radius, method=self.method)
         return [TriangleMesh(*weld(s)) for s in soups]
 
     def extract_mesh_from_code(self, code):

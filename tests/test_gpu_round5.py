@@ -196,32 +196,3 @@ def test_screening_is_off_for_logistic_occupancy_and_exact_f32():
     HO.run_packed(ws, HO.opt_cfg_from_dict(opt2), pb, 0)
     assert ws.screening_stats()["screened"] == 0
     ws.release()
-
-
-@pytest.mark.parametrize("n", [40, 80])
-def test_screened_grid_decode_gives_the_same_meshes(n):
-    """Round 5: `MeshExtractor.extract_meshes` decodes the voxel grid in one fp16 pass and re-decodes in f16x3 only the
-    corners of cells that may cross the zero level.  The completed meshes must be IDENTICAL (vertices and faces, bit for
-    bit) to the ones from the fully f16x3-decoded grid, and only a thin shell of the grid may need the exact pass."""
-    from hortimapping_amd import synthetic as S
-    from hortimapping_amd.decoder import DecoderWeights
-    from hortimapping_amd.mesher import MeshExtractor
-    for L, r0, rad in ((32, 0.04, 0.1), (32, 0.02, 0.05), (256, 0.04, 0.1)):
-        p = S.make_synthetic_decoder(L, seed=1 if L == 32 else 2, r0=r0, aniso=(1.0, 0.75, 1.3))
-        dec = DecoderWeights.from_params(p).set_precision("f16x3")
-        lat = 0.07 * torch.randn(6, L, generator=torch.Generator().manual_seed(n + L))
-        lat[0] = 0.0
-        a = MeshExtractor(dec, code_len=L, voxels_dim=n, cube_radius=rad, screen=False).extract_meshes(lat)
-        mx = MeshExtractor(dec, code_len=L, voxels_dim=n, cube_radius=rad, screen=True)
-        b = mx.extract_meshes(lat)
-        for ma, mb in zip(a, b):
-            assert ma.vertices.shape[0] > 100
-            assert np.array_equal(ma.vertices, mb.vertices) and np.array_equal(ma.faces, mb.faces)
-        frac = mx.last_screening["promoted"] / mx.last_screening["grid_points"]
-        print(f"n={n} L={L} r0={r0}: {100 * frac:.1f} % of the grid points needed the f16x3 pass")
-        assert frac < 0.35
-        # the exact-f32 decoder is not screened
-        d32 = DecoderWeights.from_params(p).set_precision("f32")
-        m32 = MeshExtractor(d32, code_len=L, voxels_dim=n, cube_radius=rad)
-        m32.extract_meshes(lat[:1])
-        assert not hasattr(m32, "last_screening")
