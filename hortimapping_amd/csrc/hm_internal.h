@@ -58,6 +58,10 @@ struct RenderCfg {
   // exactly 0 or 1 whatever its exact sdf (utils.py:125-133 clamps), so only the others go through the f16x3 forward.
   int screen;
   float screen_eps;
+  // 1: the Jacobian samples of ALL instances form ONE flat list (rb.gbase / rb.gtotal) instead of one list per instance
+  // padded to whole 64-query tiles -- the backward-only f16x3 launch then runs ceil(total / 64) tiles instead of
+  // sum_b ceil(nG[b] / 64) (C2-joint: 137 samples per instance = 2.14 tiles, launched as 3).  f16x3 render chain only.
+  int flat_jac;
 };
 
 // cpos codes of screened-far samples (instead of a slot in the promoted list)
@@ -98,6 +102,9 @@ struct RenderBuffers {
   float* JG;               // [B][nG_stride][ldJ]
   float* yG;               // [B][nG_stride]
   int* srcG;               // [B][nG_stride]   slot (index in ptsRc / sdfR order) each Jacobian sample was gathered from
+                           //                  (flat_jac: GLOBAL slot b * nR_stride + slot, list position gbase[b] + k)
+  int* gbase;              // [B] flat_jac: first list position of instance b = sum of nG over the active instances before it
+  int* gtotal;             // [1] flat_jac: total Jacobian samples of the launch
   void* maskR;             // [B][nR_stride / 64][8][512] uint2: ReLU masks saved by the f16x3 forward pass over ptsRc
   // screening (RenderCfg::screen): fp16 sdf of every ball-valid sample, the promoted samples the f16x3 forward decodes
   // instead of ptsRc (cpos then indexes THIS list), their count, and the per-group statistics

@@ -142,6 +142,8 @@ void carve(hm_workspace_s* w, Carver& c) {
   c.take(rb.yG, nG, B);
   c.take(rb.srcG, nG, B);
   c.take(rb.JR, 2 * nray * ldJ, B);
+  c.take(rb.gbase, 1, B);
+  c.take_group(rb.gtotal, 1);
   c.take(rb.sdfS, nR, B);
   c.take(rb.ptsRp, nR * 4, B);
   c.take(rb.nRp, 1, B);
@@ -261,6 +263,7 @@ RenderCfg make_render_cfg(const hm_workspace_s* ws, const hm_opt_cfg* cfg) {
   // screening applies to the f16x3 render chain under LINEAR occupancy only (logistic occupancy never saturates exactly)
   rc.screen = ((ws->dec->precision == 1 || ws->dec->precision == 2) && !ws->split_render && !cfg->log_sdf_occ) ? ws->screen_mode : 0;
   rc.screen_eps = ws->screen_eps;
+  rc.flat_jac = ((ws->dec->precision == 1 || ws->dec->precision == 2) && !ws->split_render) ? 1 : 0;
   return rc;
 }
 
@@ -297,7 +300,13 @@ int render_back(hm_workspace_s* ws, const RenderCfg& rc, const RenderBuffers& rb
   const int B = bt->B;
   int rc_ = launch_render_scan(rc, rb, d_active, B, st);
   if (rc_) return rc_;
-  if (fused_path(ws))
+  if (fused_path(ws) && rc.flat_jac)
+    // ONE flat list of Jacobian samples over all instances (k_ray_gbase / k_ray_scatter): a single virtual instance whose
+    // source slots are global indices into the [B][nR_stride] forward outputs (nR_stride % 64 == 0, so slot / 64 is the
+    // global mask tile).  The backward stages need nothing per instance (biases act in the forward only).
+    rc_ = launch_decoder_h_bwd(ws->dec, 1, nullptr, ws->c0, ws->c4, ws->ldJ, rb.ptsG, rb.gtotal, B * ws->nG_stride, rb.JG,
+                               P, rb.srcG, rb.sdfR, rb.maskR, B * ws->nR_stride, st);
+  else if (fused_path(ws))
     rc_ = launch_decoder_h_bwd(ws->dec, B, d_active, ws->c0, ws->c4, ws->ldJ, rb.ptsG, rb.nG, ws->nG_stride, rb.JG, P,
                                rb.srcG, rb.sdfR, rb.maskR, ws->nR_stride, st);
   else

@@ -359,6 +359,34 @@ __global__ __launch_bounds__(1024) void k_ray_offsets(const RenderCfg cfg, const
   }
 }
 
+// flat_jac: exclusive scan of nG over the ACTIVE instances (an inactive one keeps a stale nG from its last iteration)
+__global__ __launch_bounds__(1024) void k_ray_gbase(const RenderBuffers rb, const int* __restrict__ active, int B) {
+  __shared__ int wsum[16];
+  __shared__ int carry;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  if (tid == 0) carry = 0;
+  __syncthreads();
+  for (int base = 0; base < B; base += 1024) {
+    const int b = base + tid;
+    const int k = (b < B && (active == nullptr || active[b] != 0)) ? rb.nG[b] : 0;
+    int sk = k;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int u = __shfl_up(sk, off);
+      if (lane >= off) sk += u;
+    }
+    if (lane == 63) wsum[wv] = sk;
+    __syncthreads();
+    int pk = carry;
+    for (int w2 = 0; w2 < wv; ++w2) pk += wsum[w2];
+    if (b < B) rb.gbase[b] = pk + sk - k;
+    __syncthreads();
+    if (tid == 1023) carry = pk + sk;
+    __syncthreads();
+  }
+  if (tid == 0) *rb.gtotal = carry;
+}
+
 __global__ __launch_bounds__(256) void k_ray_scatter(const RenderCfg cfg, const RenderBuffers rb,
                                                      const int* __restrict__ active) {
   const int b = blockIdx.z, f = blockIdx.y;
@@ -376,10 +404,12 @@ __global__ __launch_bounds__(256) void k_ray_scatter(const RenderCfg cfg, const 
   const size_t src = (size_t)b * rb.nR_stride + (size_t)ray * cfg.M + lane;
   f32x4 p = reinterpret_cast<const f32x4*>(rb.ptsR)[src];
   p[3] = 1.f;
-  reinterpret_cast<f32x4*>(rb.ptsG)[(size_t)b * rb.nG_stride + dst] = p;
-  rb.srcG[(size_t)b * rb.nG_stride + dst] = rb.cpos[src];       // where the forward pass decoded this sample
-  rb.coefG[((size_t)b * rb.nG_stride + dst) * 2 + 0] = rb.coef[src * 2 + 0];
-  rb.coefG[((size_t)b * rb.nG_stride + dst) * 2 + 1] = rb.coef[src * 2 + 1];
+  // list position: per-instance lists padded to nG_stride, or ONE flat list over the instances (flat_jac)
+  const size_t at = cfg.flat_jac ? (size_t)rb.gbase[b] + dst : (size_t)b * rb.nG_stride + dst;
+  reinterpret_cast<f32x4*>(rb.ptsG)[at] = p;
+  rb.srcG[at] = cfg.flat_jac ? b * rb.nR_stride + rb.cpos[src] : rb.cpos[src];       // where the forward pass decoded this sample
+  rb.coefG[at * 2 + 0] = rb.coef[src * 2 + 0];
+  rb.coefG[at * 2 + 1] = rb.coef[src * 2 + 1];
 }
 
 // one workgroup per ray: J_d = sum_k de_ds_k * J_k, J_m = sum_k dm_ds_k * J_k over the ray's surviving samples,
@@ -396,8 +426,9 @@ __global__ __launch_bounds__(128) void k_ray_reduce(const RenderCfg cfg, const R
   const int off = rb.ray_off[rix];
   const int ldJ = L + POSE_PAD;
   const int ncol = L + 7;
-  const float* Jg = rb.JG + ((size_t)b * rb.nG_stride + off) * ldJ;
-  const float* cg = rb.coefG + ((size_t)b * rb.nG_stride + off) * 2;
+  const size_t first = (cfg.flat_jac ? (size_t)rb.gbase[b] : (size_t)b * rb.nG_stride) + off;
+  const float* Jg = rb.JG + first * ldJ;
+  const float* cg = rb.coefG + first * 2;
   float* Jd = rb.JR + ((size_t)b * 2 * nray + row) * ldJ;
   float* Jm = rb.JR + ((size_t)b * 2 * nray + nray + row) * ldJ;
   for (int c = threadIdx.x; c < ncol; c += blockDim.x) {
@@ -452,6 +483,10 @@ int launch_render_scan(const RenderCfg& cfg, const RenderBuffers& rb, const int*
   HM_CHECK_HIP(hipGetLastError());
   hipLaunchKernelGGL(k_ray_offsets, dim3(B), dim3(1024), 0, stream, cfg, rb, d_active);
   HM_CHECK_HIP(hipGetLastError());
+  if (cfg.flat_jac) {
+    hipLaunchKernelGGL(k_ray_gbase, dim3(1), dim3(1024), 0, stream, rb, d_active, B);
+    HM_CHECK_HIP(hipGetLastError());
+  }
   hipLaunchKernelGGL(k_ray_scatter, grid, dim3(256), 0, stream, cfg, rb, d_active);
   HM_CHECK_HIP(hipGetLastError());
   return 0;
