@@ -164,25 +164,28 @@ __global__ __launch_bounds__(256) void k_sample_rays(const RenderCfg cfg, const 
 // ("dead").  One wavefront per ray, lane = depth sample; cpos is rewritten from "slot in ptsRc" to "slot in the promoted
 // list ptsRp" or a CPOS_FAR_* code that k_ray_scan turns into a saturated sdf.  Bit-identical results by construction;
 // tests/test_gpu_round5.py compares whole trajectories with the screening off and counts violations in verify mode.
-__global__ __launch_bounds__(256) void k_promote(const RenderCfg cfg, const RenderBuffers rb,
-                                                 const int* __restrict__ active) {
+// Sixteen rays per 1024-thread workgroup: the promoted samples of the whole workgroup take their slots with ONE atomic
+// on the instance counter (one per wave cost 1.1 ms per iteration on the challenge configuration: 96 k atomics on 64 words).
+__global__ __launch_bounds__(1024) void k_promote(const RenderCfg cfg, const RenderBuffers rb,
+                                                  const int* __restrict__ active) {
+  __shared__ int wcnt[16];
+  __shared__ int base_s;
   const int b = blockIdx.z, f = blockIdx.y;
-  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int wv = threadIdx.x >> 6;
+  const int r = blockIdx.x * 16 + wv;
   const int lane = threadIdx.x & 63;
-  if (r >= cfg.R) return;
-  if (active != nullptr && active[b] == 0) return;
+  if (active != nullptr && active[b] == 0) return;                 // (workgroup-uniform exits)
   if (f >= rb.n_frames[b]) return;
   const int nray = rb.n_fg[b * cfg.F + f] + rb.n_bg[b * cfg.F + f];
-  if (r >= nray) return;
+  const bool ray_ok = r < cfg.R && r < nray;
   // a frame with too few ball-valid samples is skipped by k_ray_scan (loss.py:43-45): none of its samples is needed
   const bool frame_ok = rb.valid_count[b * cfg.F + f] >= cfg.min_valid;
   const int M = cfg.M;
-  const size_t at = (size_t)b * rb.nR_stride + (size_t)(f * cfg.R + r) * M + lane;
-  const bool in = lane < M;
-  f32x4 p = {0, 0, 0, 0};
+  const size_t at = (size_t)b * rb.nR_stride + (size_t)(f * cfg.R + (ray_ok ? r : 0)) * M + lane;
+  const bool in = ray_ok && lane < M;
   int slot = CPOS_NOT_VALID;
-  if (in) { p = reinterpret_cast<const f32x4*>(rb.ptsR)[at]; slot = rb.cpos[at]; }
-  const bool valid = in && p[3] != 0.f && slot >= 0;
+  if (in) slot = rb.cpos[at];
+  const bool valid = in && slot >= 0;                 // k_sample_rays: slot >= 0 <=> ball-valid (w of ptsR is 1)
   const float st = valid ? rb.sdfS[(size_t)b * rb.nR_stride + slot] : 0.f;
   const float lim = cfg.occ_th + cfg.screen_eps;
   const bool far_in = valid && st < -lim, far_out = valid && st > lim;
@@ -193,19 +196,24 @@ __global__ __launch_bounds__(256) void k_promote(const RenderCfg cfg, const Rend
   const bool dead = valid && lane > first_in && isfinite(st);
   const bool promote = valid && frame_ok && !dead && !far_in && !far_out;     // includes non-finite screening values
   const unsigned long long pm = __ballot(promote);
-  int base = 0;
-  if (pm != 0ull) {
-    if (lane == 0) base = atomicAdd(&rb.nRp[b], __popcll(pm));
-    base = __shfl(base, 0);
+  if (lane == 0) wcnt[wv] = __popcll(pm);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int tot = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) tot += wcnt[i];
+    base_s = tot > 0 ? atomicAdd(&rb.nRp[b], tot) : 0;
   }
+  __syncthreads();
+  int base = base_s;
+  for (int i = 0; i < wv; ++i) base += wcnt[i];
   if (valid) {
     int code;
     if (promote) {
       code = base + __popcll(pm & ((1ull << lane) - 1ull));
-      reinterpret_cast<f32x4*>(rb.ptsRp)[(size_t)b * rb.nR_stride + code] = p;
+      reinterpret_cast<f32x4*>(rb.ptsRp)[(size_t)b * rb.nR_stride + code] = reinterpret_cast<const f32x4*>(rb.ptsR)[at];
     } else {
-      code = (far_in || dead) ? CPOS_FAR_INSIDE : (far_out ? CPOS_FAR_OUTSIDE : CPOS_FAR_OUTSIDE);
-      // (!frame_ok: the code is never read)
+      code = (far_in || dead) ? CPOS_FAR_INSIDE : CPOS_FAR_OUTSIDE;          // (!frame_ok: the code is never read)
     }
     rb.cpos[at] = code;
   }
@@ -218,8 +226,8 @@ __global__ __launch_bounds__(256) void k_promote(const RenderCfg cfg, const Rend
     }
     const unsigned long long vm = __ballot(valid && frame_ok), dm = __ballot(dead && frame_ok), bm = __ballot(bad);
     if (lane == 0) {
-      atomicAdd(&rb.screen_stats[0], (unsigned long long)__popcll(vm));
-      atomicAdd(&rb.screen_stats[1], (unsigned long long)__popcll(pm));
+      if (vm) atomicAdd(&rb.screen_stats[0], (unsigned long long)__popcll(vm));
+      if (pm) atomicAdd(&rb.screen_stats[1], (unsigned long long)__popcll(pm));
       if (bm) atomicAdd(&rb.screen_stats[2], (unsigned long long)__popcll(bm));
       if (dm) atomicAdd(&rb.screen_stats[3], (unsigned long long)__popcll(dm));
     }
@@ -470,8 +478,8 @@ int launch_render_front(const RenderCfg& cfg, const RenderBuffers& rb, const flo
 
 int launch_render_promote(const RenderCfg& cfg, const RenderBuffers& rb, const int* d_active, int B,
                           hipStream_t stream) {
-  dim3 grid((cfg.R + 3) / 4, cfg.F, B);
-  hipLaunchKernelGGL(k_promote, grid, dim3(256), 0, stream, cfg, rb, d_active);
+  dim3 grid((cfg.R + 15) / 16, cfg.F, B);
+  hipLaunchKernelGGL(k_promote, grid, dim3(1024), 0, stream, cfg, rb, d_active);
   HM_CHECK_HIP(hipGetLastError());
   return 0;
 }
