@@ -11,6 +11,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <mutex>
 #include <vector>
 
 #include "../../include/hortimapping_amd.h"
@@ -51,7 +52,7 @@ struct hm_workspace_s {
   // instance groups: internal streams + fork / join events; 0 = automatic group count
   hipStream_t gstream[G_MAX];
   hipEvent_t ev_fork, ev_join[G_MAX], ev_stagger[G_MAX];
-  int n_gres;                     // group streams (+ their join / stagger events) created so far
+  int n_gres;                     // join / stagger events of the groups created so far (the streams come from a process pool)
   bool have_fork;                 // ev_fork exists
   int groups_override;
   int host_pacing;                // 1: stay <= LAG + 1 iterations ahead of the device when early exits are possible
@@ -434,30 +435,58 @@ extern "C" int hm_workspace_create(hm_decoder_s* dec, const hm_limits* lim, hm_w
 }
 
 namespace {
-// streams + fork / join events of the instance groups, created on first use (a workspace that only ever sees small
-// batches or the functional API never needs them)
-// Creates what is missing for G groups and nothing more; a failure half way leaves every handle created so far
-// registered (n_gres / have_fork), so that a later call resumes from there and hm_workspace_destroy frees them all.
+// The internal streams of the instance groups come from ONE process-wide pool per device (G_MAX streams, created on first
+// use, kept for the life of the process), not from the workspace: the runtime multiplexes a process's streams onto four
+// hardware queues, and every additional workspace with streams of its own -- the drop-in Optimizer's cache, its exact-f32
+// retry workspace, a second decoder, the nested runs of bench.py -- shifted the mapping until the two groups of a call
+// shared a queue and ran back to back (round 5: `c2_joint2048` 92 instances/s as a nested run of the bench process against
+// 101-103 in a fresh process, same box).  Sharing the pool is safe: a call forks from and joins back into the caller's stream by
+// events, and two calls in flight at once (two workspaces, two host threads) merely take turns on a group stream.
+constexpr int HM_MAX_DEV = 16;
+std::mutex g_pool_mu;
+hipStream_t g_pool[HM_MAX_DEV][hm_workspace_s::G_MAX];
+int g_pool_n[HM_MAX_DEV];
+
+int pool_stream(int g, hipStream_t* out) {
+  int dev = 0;
+  HM_CHECK_HIP(hipGetDevice(&dev));
+  if (dev < 0 || dev >= HM_MAX_DEV) { hm_set_error("device index %d beyond the group-stream pool", dev); return -2; }
+  std::lock_guard<std::mutex> lk(g_pool_mu);
+  while (g_pool_n[dev] <= g) {
+    hipStream_t s = nullptr;
+    hipError_t e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+    if (e != hipSuccess) { hm_set_error("creating the stream of instance group %d failed: %s", g_pool_n[dev], hipGetErrorString(e)); return -2; }
+    g_pool[dev][g_pool_n[dev]++] = s;
+  }
+  *out = g_pool[dev][g];
+  return 0;
+}
+
+// fork / join events of the instance groups (per workspace), created on first use (a workspace that only ever sees small
+// batches or the functional API never needs them).  Creates what is missing for G groups and nothing more; a failure half
+// way leaves every handle created so far registered (n_gres / have_fork), so that a later call resumes from there and
+// hm_workspace_destroy frees them all.
 int ensure_group_resources(hm_workspace_s* w, int G) {
   if (!w->have_fork) {
     HM_CHECK_HIP(hipEventCreateWithFlags(&w->ev_fork, hipEventDisableTiming));
     w->have_fork = true;
   }
+  for (int g = 0; g < G; ++g) {
+    const int rc = pool_stream(g, &w->gstream[g]);      // (re-fetched every call: the workspace may have moved to another device's context)
+    if (rc) return rc;
+  }
   while (w->n_gres < G) {
     const int g = w->n_gres;
-    hipStream_t s = nullptr;
     hipEvent_t ej = nullptr, es = nullptr;
-    hipError_t e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&ej, hipEventDisableTiming);
+    hipError_t e = hipEventCreateWithFlags(&ej, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&es, hipEventDisableTiming);
     if (e != hipSuccess) {
       if (es) (void)hipEventDestroy(es);
       if (ej) (void)hipEventDestroy(ej);
-      if (s) (void)hipStreamDestroy(s);
-      hm_set_error("creating the stream / events of instance group %d failed: %s", g, hipGetErrorString(e));
+      hm_set_error("creating the events of instance group %d failed: %s", g, hipGetErrorString(e));
       return -2;
     }
-    w->gstream[g] = s; w->ev_join[g] = ej; w->ev_stagger[g] = es;
+    w->ev_join[g] = ej; w->ev_stagger[g] = es;
     w->n_gres = g + 1;
   }
   return 0;
@@ -511,7 +540,7 @@ extern "C" int hm_workspace_destroy(hm_workspace_s* w) {
   for (hipEvent_t e : w->ev) (void)hipEventDestroy(e);
   if (w->act_ready) for (int i = 0; i < hm_workspace_s::G_MAX * hm_workspace_s::N_ACT; ++i) (void)hipEventDestroy((&w->ev_act[0][0])[i]);
   if (w->h_act_count) (void)hipHostFree(w->h_act_count);
-  for (int g = 0; g < w->n_gres; ++g) { (void)hipStreamDestroy(w->gstream[g]); (void)hipEventDestroy(w->ev_join[g]); (void)hipEventDestroy(w->ev_stagger[g]); }
+  for (int g = 0; g < w->n_gres; ++g) { (void)hipEventDestroy(w->ev_join[g]); (void)hipEventDestroy(w->ev_stagger[g]); }   // (streams: process pool)
   if (w->have_fork) (void)hipEventDestroy(w->ev_fork);
   (void)hipFree(w->d_blob);
   if (w->d_maskR) (void)hipFree(w->d_maskR);

@@ -177,8 +177,10 @@ int hm_workspace_counters_read(hm_workspace_t ws, long long* out5, void* stream)
  *
  * Streams.  The work is ordered after everything already on `stream` and before everything the caller enqueues on it
  * afterwards.  A batch of >= 16 instances is cut into instance groups (hm_workspace_set_groups) that run on INTERNAL
- * non-blocking streams of the workspace, forked from and joined back into `stream` by events; the caller's stream sees
- * one fork and one join.  A workspace must not be used by two calls at the same time.
+ * non-blocking streams (a process-wide pool of at most four per device, shared by all workspaces so that the number of
+ * streams -- and with it their mapping onto the runtime's hardware queues -- does not grow with the number of workspaces),
+ * forked from and joined back into `stream` by events; the caller's stream sees one fork and one join.  A workspace must
+ * not be used by two calls at the same time; calls on DIFFERENT workspaces may overlap (they take turns on the pool).
  *
  * Host behaviour -- this call is NOT always a pure enqueue:
  *   - every epsilon_* == 0 (forced iterations): all cfg->max_iter iterations are enqueued and the call returns without
