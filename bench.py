@@ -574,9 +574,10 @@ def main(argv=None, emit=True):
     full_line = (not stub and not args.no_exact and world == 1 and not strong and args.decoder == "analytic" and L == 256
                  and args.workload == "c2_joint" and per_gpu == 64)
     if full_line:
-        # The two OTHER readings of the metric's "2048 pts/instance", run directly after the primary workload (round 5: as the
-        # eleventh workload of the process the joint-2048 reading came out 8-10 % lower than in a fresh process on the same box --
-        # three minutes of sustained load on a power-capped socket -- so the three readings now share the same conditions).
+        # The two OTHER readings of the metric's "2048 pts/instance", run directly after the primary workload so that the three
+        # readings share the same conditions.  (Round 5: as nested runs of this process they used to come out 5-10 % below a
+        # fresh process -- not heat: a second workspace with group streams of its own shifted the stream -> hardware-queue
+        # mapping; the library now takes the group streams from one process-wide pool, hm_optimize.hip.)
         # SURVEY.md 8d "run twice": C2-sdf = the shape-only loop (shape_opt_deepsdf) on 2048 surface points per instance
         o4 = main(["--steps", "3", "--warmup", "1", "--iters", str(args.iters), "--workload", "c2_sdf", "--precision",
                    args.precision, "--no-exact", "--no-cpu-baseline", "--groups", str(args.groups)], emit=False)
