@@ -590,6 +590,12 @@ def main(argv=None, emit=True):
         out["c2_joint2048"] = {"value": o6["value"], "unit": o6["unit"], "steps": 3, "dtype": o6["dtype"],
                                "ms_per_step": o6["ms_per_step"], "workload": o6["config"]["workload"],
                                "roofline": o6["roofline"]}
+    if full_line:
+        out["metric_readings"] = {
+            "note": "the metric's '200 iters, 2048 pts' read three ways; `value` is the first (SURVEY.md 8d's C2-joint)",
+            "c2_joint (1024 surface pts + 64 rays x 16 samples = 2048 decoder pts / iteration, joint latent + Sim(3))": out["value"],
+            "c2_sdf (2048 surface pts, shape-only loop)": out["c2_sdf"]["value"],
+            "c2_joint2048 (2048 surface pts + the 64 x 16 render block, joint latent + Sim(3))": out["c2_joint2048"]["value"]}
     if not stub and not args.no_exact and world == 1 and not strong:
         # the same job in the other decoder arithmetics, one timed step each, for reference next to the primary line
         for other, key in (("f32", "exact_f32"), ("f16x3f_f16b", "mixed_f16x3f_f16b"), ("f16", "plain_f16")):
