@@ -146,7 +146,7 @@ int launch_decoder_p(const hm_decoder_s* dec, int B, const float* d_pts, const i
                      int pose_dim, int mode, hipStream_t stream, int tag);
 
 int launch_normal_eq(const RowSegment* segs, int n_seg, int L, int B, const int* d_active, float* d_Hext,
-                     hipStream_t stream);
+                     hipStream_t stream, int split_f16 = 0);    // split_f16: K4h (fp16 MFMA on split operands) for the f16x3 arithmetics
 
 int launch_solve_update(const SolveArgs& args, int B, hipStream_t stream);
 

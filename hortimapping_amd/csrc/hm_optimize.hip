@@ -56,6 +56,7 @@ struct hm_workspace_s {
   bool have_fork;                 // ev_fork exists
   int groups_override;
   int host_pacing;                // 1: stay <= LAG + 1 iterations ahead of the device when early exits are possible
+  int k4_split;                   // 1 (default): the f16x3 arithmetics run the normal equations on the fp16 matrix cores (K4h)
   // test / A-B switches, scoped to THIS workspace: the override set by hm_workspace_set_debug (-1 = follow the process
   // default of hm_debug_split_render / hm_debug_force_direct_solve) and the value snapshotted when an entry point is
   // called -- one call never sees a switch change under it (a mask-less forward paired with a mask-reading backward)
@@ -397,7 +398,7 @@ extern "C" int hm_workspace_create(hm_decoder_s* dec, const hm_limits* lim, hm_w
   w->nR_stride = round_up(w->nray * w->lim.max_samples, TQ);
   const int cap = lim->max_grad_samples > 0 ? lim->max_grad_samples : w->nray * w->lim.max_samples;
   w->nG_stride = round_up(cap, TQ);
-  w->n_gres = 0; w->have_fork = false; w->groups_override = 0; w->host_pacing = 1;
+  w->n_gres = 0; w->have_fork = false; w->groups_override = 0; w->host_pacing = 1; w->k4_split = 1;
   Carver size_pass;
   carve(w, size_pass);
   w->blob_bytes = size_pass.off + 256;
@@ -733,7 +734,7 @@ int opt_iteration(OptRun& r, const hm_opt_cfg* cfg, int it, hipEvent_t after_mai
     segs[2] = RowSegment{rb.JR, stride, ws->nray, rb.V, 0, nullptr, cfg->w_mask, 0.f};   // mask never robust (:158)
     n_seg = 3;
   }
-  rc = launch_normal_eq(segs, n_seg, L, B, ws->active, ws->Hext, st);
+  rc = launch_normal_eq(segs, n_seg, L, B, ws->active, ws->Hext, st, (ws->dec->precision == 1 || ws->dec->precision == 2) ? own->k4_split : 0);
   if (rc) return rc;
 
   SolveArgs sa;
@@ -787,6 +788,13 @@ int group_count(const hm_workspace_s* ws, int B, const hm_debug* dbg) {
 }
 
 }  // namespace
+
+// A/B + tests: 0 = the f16x3 arithmetics keep the fp32-input normal-equation kernel (rounds 1-4), 1 = K4h (default)
+extern "C" int hm_workspace_set_k4_split(hm_workspace_s* w, int on) {
+  if (w == nullptr) { hm_set_error("null workspace"); return -1; }
+  w->k4_split = on ? 1 : 0;
+  return 0;
+}
 
 extern "C" int hm_workspace_set_host_pacing(hm_workspace_s* w, int on) {
   if (w == nullptr) { hm_set_error("null workspace"); return -1; }

@@ -20,6 +20,9 @@ extern "C" {
  * takes the blocked-Cholesky fallback of the solve kernel.  -1 = follow the process default. */
 int hm_workspace_set_debug(hm_workspace_t ws, int split_render, int force_direct_solve);
 /* (hm_workspace_set_groups moved to the product header in round 5: the drop-in Optimizer and bench.py use it.) */
+/* Normal equations of the f16x3 arithmetics: 1 (default) = K4h, fp16 matrix cores on split operands (hm_normal_eq.hip);
+ * 0 = the fp32-input kernel of rounds 1-4 (what exact f32 always runs).  A/B and the test that both agree to fp32 rounding. */
+int hm_workspace_set_k4_split(hm_workspace_t ws, int on);
 
 /* ---- performance-analysis aids (not part of the drop-in surface): when a device buffer is registered, block 0 of
  * the f16x3 decoder kernel / of the solve kernel writes shader-clock stamps per stage into it (scripts/gpu_trace_*.py). */

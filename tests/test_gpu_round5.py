@@ -196,3 +196,45 @@ def test_screening_is_off_for_logistic_occupancy_and_exact_f32():
     HO.run_packed(ws, HO.opt_cfg_from_dict(opt2), pb, 0)
     assert ws.screening_stats()["screened"] == 0
     ws.release()
+
+
+def test_normal_equations_on_the_fp16_matrix_cores_agree_with_the_fp32_kernel():
+    """K4h (round 5): in the f16x3 arithmetics the normal equations run on the fp16 matrix cores with split operands.  Same
+    rows in, so H and b must agree with the fp32-input kernel to fp32 rounding (products exact, 2^-22 dropped term) -- checked on
+    the damped system of a full-size C2-joint iteration (L = 256, 1024 + V + V rows, Huber weights on) and on a wild_pepper-sized
+    L = 32 instance with three segments of very different weights; whole trajectories stay within the noise tolerances of the
+    golden tests (the rest of the suite runs with K4h on)."""
+    import ctypes
+    from hortimapping_amd import _lib, optimizer as HO, synthetic as S, workloads as W
+    from hortimapping_amd.decoder import DecoderWeights
+    lib = _lib.lib()
+    lib.hm_workspace_set_k4_split.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    for L, it, kw in ((256, 1, dict(n_pts=1024, n_frames=1, n_fg=32, n_bg=32)), (32, 1, dict(n_pts=2000, n_frames=4, n_fg=120, n_bg=100))):
+        p = S.make_synthetic_decoder(L, seed=2, r0=0.04, aniso=(1.0, 0.75, 1.3))
+        dec = DecoderWeights.from_params(p).set_precision("f16x3")
+        Ws, bs = S.fold_weight_norm(p)
+        fac = W.gpu_sdf_factory(dec)
+        insts = [W.to_instance(S.make_instance(Ws, bs, L, i, sdf_fn_factory=fac, **kw)) for i in range(3)]
+        opt = W.c2_opt_cfg(max_iter=it, n_sample_on_ray=16 if L == 256 else 30, n_frame=kw["n_frames"])
+        opt["robust_iter"] = 0                                   # Huber weights on in the one iteration compared
+        hcfg = HO.opt_cfg_from_dict(opt)
+        out = {}
+        for split in (0, 1):
+            pb = HO.PackedBatch(insts, L, kw["n_frames"], "cuda")
+            ws = HO.Workspace(dec, pb.B, pb.points_stride, pb.F, pb.R, hcfg.n_sample_on_ray)
+            assert lib.hm_workspace_set_k4_split(ws.handle, split) == 0
+            dbg = {}
+            HO.run_packed(ws, hcfg, pb, 0, dbg)
+            torch.cuda.synchronize()
+            out[split] = (dbg["A"].cpu().numpy(), dbg["b"].cpu().numpy(), pb.latent.cpu().numpy(), pb.T_ow.cpu().numpy())
+            ws.release()
+        for b in range(3):
+            A0, A1 = np.tril(out[0][0][b]), np.tril(out[1][0][b])
+            # ONE iteration from identical inputs: the two kernels see the same rows, so the damped systems differ by the
+            # summation arithmetic only (fp32 MFMA chain vs exact fp16 products + fp32 accumulation, 2^-22 dropped term)
+            assert np.isfinite(A1).all()
+            eA = np.abs(A1 - A0).max() / np.abs(A0).max()
+            eb = np.abs(out[1][1][b] - out[0][1][b]).max() / np.abs(out[0][1][b]).max()
+            print(f"L={L} inst {b}: K4h vs fp32 K4: H {eA:.1e}, b {eb:.1e}")
+            assert eA <= 2e-6 and eb <= 2e-6, (L, b, eA, eb)
+            assert np.abs(out[1][2][b] - out[0][2][b]).max() <= 1e-4 * max(np.abs(out[0][2][b]).max(), 1e-3)
