@@ -264,6 +264,7 @@ def parse_args(argv=None):
     ap.add_argument("--groups", type=int, default=0,
                     help="instance groups per hm_optimize_batch call (internal streams): 0 = automatic (2 from 16 instances on), "
                          "1 = one stream (the schedule of rounds 1-3; use it under rocprofv3 for un-overlapped kernel durations)")
+    ap.add_argument("--k4", type=int, default=-1, help=argparse.SUPPRESS)             # A/B: hm_workspace_set_k4_split (0 fp32, 1 K4h, 2 K4w)
     ap.add_argument("--split-render", action="store_true", help=argparse.SUPPRESS)   # A/B: round-2 launch sequence (hm_debug_split_render)
     ap.add_argument("--stub-cpu", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--share-gpu", action="store_true", help=argparse.SUPPRESS)   # tests: N ranks on ONE GPU over gloo
@@ -380,6 +381,9 @@ def main(argv=None, emit=True):
             lib.hm_debug_split_render(1)
         lib.hm_workspace_set_groups.argtypes = [ctypes.c_void_p, ctypes.c_int]
         lib.hm_workspace_set_groups(ws.handle, args.groups)
+        if args.k4 >= 0:
+            lib.hm_workspace_set_k4_split.argtypes = [ctypes.c_void_p, ctypes.c_int]
+            lib.hm_workspace_set_k4_split(ws.handle, args.k4)
         lib.hm_workspace_profile.argtypes = [ctypes.c_void_p, ctypes.c_int]
         lib.hm_workspace_profile_read.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double),
                                                   ctypes.POINTER(ctypes.c_longlong)]

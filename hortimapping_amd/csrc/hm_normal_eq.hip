@@ -151,13 +151,28 @@ __global__ __launch_bounds__(256) void k_normal_eq(const NormalEqArgs a) {
 // decoder itself (the exact-f32 arithmetic keeps k_normal_eq).  Same tiling, same XCD map, fixed summation order.
 typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
 
+// hi = f16(v), lo = f16((v - hi) 2^11) for eight values: per PAIR one packed conversion, one packed multiply and the two
+// mixed-precision fmas of hm_decoder_h.hip (lo = f16(hi * -2^11 + v * 2^11): an exact fp32 fma, ONE rounding -- bit-identical
+// to the subtract-scale-convert form, a third of its instructions).  `w` scales the values first (row weights of the B side).
+typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2k __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void split8(const float (&v)[8], h16x8& hi, h16x8& lo) {
+  uint32_t hw[4], lw[4];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const _Float16 h = (_Float16)v[j];
-    hi[j] = h;
-    lo[j] = (_Float16)((v[j] - (float)h) * 2048.f);
+  for (int j = 0; j < 4; ++j) {
+    const f32x2k x = {v[2 * j], v[2 * j + 1]};
+    const h16x2 hp = __builtin_convertvector(x, h16x2);
+    const f32x2k sx = x * 2048.f;
+    uint32_t hpk, d;
+    __builtin_memcpy(&hpk, &hp, 4);
+    const float cneg = -2048.f;
+    asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixhi_f16 %0, %1, %2, %4 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+        : "=&v"(d) : "v"(hpk), "s"(cneg), "v"(sx[0]), "v"(sx[1]));
+    hw[j] = hpk; lw[j] = d;
   }
+  __builtin_memcpy(&hi, hw, 16);
+  __builtin_memcpy(&lo, lw, 16);
 }
 
 __global__ __launch_bounds__(256) void k_normal_eq_h(const NormalEqArgs a) {
@@ -271,6 +286,10 @@ __global__ __launch_bounds__(256) void k_normal_eq_h(const NormalEqArgs a) {
   }
 }
 
+#ifdef HM_EXPERIMENTAL      // K4w: one workgroup per instance for the whole block triangle -- half the CU-time of K4h, but 141 us of
+#include "experimental/hm_normal_eq_w.inc"   // latency on B CUs: -2.7 % end to end (profiles/r05_k4_ab.txt); not in the product library
+#endif
+
 namespace hm {
 
 int launch_normal_eq(const RowSegment* segs, int n_seg, int L, int B, const int* d_active, float* d_Hext,
@@ -283,6 +302,10 @@ int launch_normal_eq(const RowSegment* segs, int n_seg, int L, int B, const int*
   const int ntp = ntile * (ntile + 1) / 2;
   const int inst_per_xcd = (B + 7) / 8;
   const int grid = inst_per_xcd * ntp * 8;
+#ifdef HM_EXPERIMENTAL
+  if (split_f16 == 2) hipLaunchKernelGGL(k_normal_eq_w, dim3(B), dim3(512), 0, stream, a);
+  else
+#endif
   if (split_f16) hipLaunchKernelGGL(k_normal_eq_h, dim3(grid), dim3(256), 0, stream, a);
   else hipLaunchKernelGGL(k_normal_eq, dim3(grid), dim3(256), 0, stream, a);
   HM_CHECK_HIP(hipGetLastError());

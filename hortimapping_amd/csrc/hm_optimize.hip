@@ -56,7 +56,7 @@ struct hm_workspace_s {
   bool have_fork;                 // ev_fork exists
   int groups_override;
   int host_pacing;                // 1: stay <= LAG + 1 iterations ahead of the device when early exits are possible
-  int k4_split;                   // 1 (default): the f16x3 arithmetics run the normal equations on the fp16 matrix cores (K4h)
+  int k4_split;                   // f16x3 arithmetics: 0 fp32-input kernel, 1 K4h (tiles; default), 2 K4w (experimental builds only, else = 1)
   // test / A-B switches, scoped to THIS workspace: the override set by hm_workspace_set_debug (-1 = follow the process
   // default of hm_debug_split_render / hm_debug_force_direct_solve) and the value snapshotted when an entry point is
   // called -- one call never sees a switch change under it (a mask-less forward paired with a mask-reading backward)
@@ -792,7 +792,7 @@ int group_count(const hm_workspace_s* ws, int B, const hm_debug* dbg) {
 // A/B + tests: 0 = the f16x3 arithmetics keep the fp32-input normal-equation kernel (rounds 1-4), 1 = K4h (default)
 extern "C" int hm_workspace_set_k4_split(hm_workspace_s* w, int on) {
   if (w == nullptr) { hm_set_error("null workspace"); return -1; }
-  w->k4_split = on ? 1 : 0;
+  w->k4_split = (on < 0 || on > 2) ? 0 : on;
   return 0;
 }
 

@@ -219,7 +219,7 @@ def test_normal_equations_on_the_fp16_matrix_cores_agree_with_the_fp32_kernel():
         opt["robust_iter"] = 0                                   # Huber weights on in the one iteration compared
         hcfg = HO.opt_cfg_from_dict(opt)
         out = {}
-        for split in (0, 1):
+        for split in (0, 1, 2):
             pb = HO.PackedBatch(insts, L, kw["n_frames"], "cuda")
             ws = HO.Workspace(dec, pb.B, pb.points_stride, pb.F, pb.R, hcfg.n_sample_on_ray)
             assert lib.hm_workspace_set_k4_split(ws.handle, split) == 0
@@ -228,13 +228,15 @@ def test_normal_equations_on_the_fp16_matrix_cores_agree_with_the_fp32_kernel():
             torch.cuda.synchronize()
             out[split] = (dbg["A"].cpu().numpy(), dbg["b"].cpu().numpy(), pb.latent.cpu().numpy(), pb.T_ow.cpu().numpy())
             ws.release()
-        for b in range(3):
-            A0, A1 = np.tril(out[0][0][b]), np.tril(out[1][0][b])
-            # ONE iteration from identical inputs: the two kernels see the same rows, so the damped systems differ by the
-            # summation arithmetic only (fp32 MFMA chain vs exact fp16 products + fp32 accumulation, 2^-22 dropped term)
-            assert np.isfinite(A1).all()
-            eA = np.abs(A1 - A0).max() / np.abs(A0).max()
-            eb = np.abs(out[1][1][b] - out[0][1][b]).max() / np.abs(out[0][1][b]).max()
-            print(f"L={L} inst {b}: K4h vs fp32 K4: H {eA:.1e}, b {eb:.1e}")
-            assert eA <= 2e-6 and eb <= 2e-6, (L, b, eA, eb)
-            assert np.abs(out[1][2][b] - out[0][2][b]).max() <= 1e-4 * max(np.abs(out[0][2][b]).max(), 1e-3)
+        for split, name in ((1, "K4h (64 x 64 tiles)"), (2, "K4w in experimental builds, K4h otherwise")):
+            for b in range(3):
+                A0, A1 = np.tril(out[0][0][b]), np.tril(out[split][0][b])
+                # ONE iteration from identical inputs: the kernels see the same rows, so the damped systems differ by the
+                # summation arithmetic only (fp32 MFMA chain vs exact fp16 products + fp32 accumulation, 2^-22 dropped term;
+                # K4w also takes the square root of the row weights)
+                assert np.isfinite(A1).all()
+                eA = np.abs(A1 - A0).max() / np.abs(A0).max()
+                eb = np.abs(out[split][1][b] - out[0][1][b]).max() / np.abs(out[0][1][b]).max()
+                print(f"L={L} inst {b}: {name} vs fp32 K4: H {eA:.1e}, b {eb:.1e}")
+                assert eA <= 2e-6 and eb <= 2e-6, (L, b, name, eA, eb)
+                assert np.abs(out[split][2][b] - out[0][2][b]).max() <= 1e-4 * max(np.abs(out[0][2][b]).max(), 1e-3)
