@@ -26,6 +26,10 @@ def _declare(lib):
     lib.hm_decoder_create.restype = c_int
     lib.hm_decoder_create.argtypes = [c_int, ctypes.POINTER(c_float_p), ctypes.POINTER(c_float_p),
                                       ctypes.POINTER(c_void_p)]
+    lib.hm_decoder_create_arch.restype = c_int
+    lib.hm_decoder_create_arch.argtypes = [c_void_p, ctypes.POINTER(c_float_p), ctypes.POINTER(c_float_p),
+                                           ctypes.POINTER(c_float_p), ctypes.POINTER(c_float_p),
+                                           ctypes.POINTER(c_void_p)]
     lib.hm_decoder_destroy.restype = c_int
     lib.hm_decoder_destroy.argtypes = [c_void_p]
     lib.hm_decoder_latent_dim.restype = c_int

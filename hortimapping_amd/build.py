@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "..", "build", "obj")
 LIB = os.path.join(HERE, "libhortihip.so")
-SOURCES = ["hm_pack.hip", "hm_decoder.hip", "hm_decoder_h.hip", "hm_decoder_p.hip", "hm_normal_eq.hip", "hm_solve.hip", "hm_render.hip",
+SOURCES = ["hm_pack.hip", "hm_decoder.hip", "hm_decoder_h.hip", "hm_decoder_p.hip", "hm_decoder_any.hip", "hm_normal_eq.hip", "hm_solve.hip", "hm_render.hip",
            "hm_optimize.hip", "hm_mesh.hip", "hm_metrics.hip", "hm_prep.hip", "hm_debug.hip", "hm_api.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I", CSRC]
 

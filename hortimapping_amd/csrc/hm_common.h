@@ -60,6 +60,26 @@ struct DecoderDev {
   const float* b4;               // [512]
 };
 
+// ---- any-architecture decoder (hm_decoder_any.hip): the layer table of deepsdf/networks/deep_sdf_decoder.py:29-72 ----
+#define HM_ANY_MAX_LIN 16       // Linear layers (== HM_MAX_LIN of include/hortimapping_amd.h)
+#define HM_ANY_MAX_WIDTH 512    // widest layer input / output
+
+struct AnyLayer {
+  const float* wf;     // forward A operand  (W,   rows = out_dim, K = in_dim),  pack_stage order, zero padded
+  const float* wb;     // backward A operand (W^T, rows = in_dim,  K = out_dim), pack_stage order, zero padded
+  const float* bias;   // [512], zero padded
+  const float* gamma;  // [512] LayerNorm weight (layers with ln), zero padded
+  const float* beta;   // [512] LayerNorm bias
+  int in_dim, out_dim;
+  int cat;             // input of this layer: 0 = previous output, 1 = cat[., z, xyz] (latent_in), 2 = cat[., xyz] (xyz_in_all)
+  int ln;              // LayerNorm between this Linear and its ReLU
+};
+
+struct AnyDev {
+  int L, n_lin, use_tanh, n_ln;
+  AnyLayer lay[HM_ANY_MAX_LIN];
+};
+
 }  // namespace hm
 
 struct hm_decoder_s {
@@ -70,6 +90,9 @@ struct hm_decoder_s {
   void* d_blob;        // one allocation holding every packed array
   size_t blob_bytes;
   int L;
+  int generic;         // 1: built by hm_decoder_create_arch: `any` is valid, `dev` is not; exact fp32 only
+  hm::AnyDev any;
+  void* d_any_slab;    // per-workgroup scratch of the any-architecture kernel (LayerNorm saves + d sdf / d z block)
 };
 
 #define HM_CHECK_HIP(expr)                                                        \

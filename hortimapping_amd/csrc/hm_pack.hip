@@ -16,6 +16,7 @@
 #include <math.h>
 
 #include "hm_common.h"
+#include "hm_internal.h"
 
 using namespace hm;
 
@@ -203,9 +204,88 @@ extern "C" int hm_decoder_create(int latent_dim, const float* const* W, const fl
   return 0;
 }
 
+// Layer table of an arbitrary reference `Decoder` (deep_sdf_decoder.py:29-72), mirrored from include/hortimapping_amd.h
+struct hm_decoder_arch {
+  int latent_dim, n_lin, use_tanh;
+  int in_dim[HM_ANY_MAX_LIN], out_dim[HM_ANY_MAX_LIN], cat[HM_ANY_MAX_LIN], layer_norm[HM_ANY_MAX_LIN];
+};
+
+extern "C" int hm_decoder_create_arch(const hm_decoder_arch* arch, const float* const* W, const float* const* bias,
+                                      const float* const* ln_weight, const float* const* ln_bias, hm_decoder_s** out) {
+  if (out == nullptr || arch == nullptr || W == nullptr || bias == nullptr) { hm_set_error("null argument"); return -1; }
+  const int L = arch->latent_dim, n = arch->n_lin, D0 = L + 3;
+  if (L < 32 || L > MAX_L || (L % 32) != 0) {
+    hm_set_error("latent_dim %d unsupported: need a multiple of 32 in [32, %d]", L, MAX_L); return -1; }
+  if (n < 2 || n > HM_ANY_MAX_LIN) { hm_set_error("n_lin %d unsupported: need 2 .. %d Linear layers", n, HM_ANY_MAX_LIN); return -1; }
+  int n_ln = 0;
+  for (int l = 0; l < n; ++l) {
+    const int in = arch->in_dim[l], od = arch->out_dim[l], cat = arch->cat[l];
+    if (W[l] == nullptr || bias[l] == nullptr) { hm_set_error("lin%d: null weight / bias", l); return -1; }
+    if (in < 1 || in > HM_ANY_MAX_WIDTH || od < 1 || od > HM_ANY_MAX_WIDTH) {
+      hm_set_error("lin%d: %d -> %d outside the supported widths 1 .. %d", l, in, od, HM_ANY_MAX_WIDTH); return -1; }
+    if (cat < 0 || cat > 2 || (l == 0 && cat != 0)) { hm_set_error("lin%d: bad concatenation code %d", l, cat); return -1; }
+    const int expect = l == 0 ? D0 : arch->out_dim[l - 1] + (cat == 1 ? D0 : (cat == 2 ? 3 : 0));
+    if (in != expect) {   // deep_sdf_decoder.py:41-47: out_dim of the previous layer leaves room for the concatenation
+      hm_set_error("lin%d: in_dim %d does not match the previous layer's output (+ concatenation) %d", l, in, expect); return -1; }
+    if (arch->layer_norm[l]) {
+      if (l == n - 1) { hm_set_error("lin%d: LayerNorm on the last layer is never applied by Decoder.forward", l); return -1; }
+      if (ln_weight == nullptr || ln_bias == nullptr || ln_weight[l] == nullptr || ln_bias[l] == nullptr) {
+        hm_set_error("lin%d: LayerNorm parameters missing", l); return -1; }
+      ++n_ln;
+    }
+  }
+  if (arch->out_dim[n - 1] != 1) { hm_set_error("the last layer must have one output (sdf)"); return -1; }
+
+  Blob blob;
+  size_t o_wf[HM_ANY_MAX_LIN], o_wb[HM_ANY_MAX_LIN], o_b[HM_ANY_MAX_LIN], o_g[HM_ANY_MAX_LIN], o_be[HM_ANY_MAX_LIN];
+  for (int l = 0; l < n; ++l) {
+    const int in = arch->in_dim[l], od = arch->out_dim[l];
+    const float* Wl = W[l];
+    o_wf[l] = pack_stage(blob, 0, (od + 31) / 32, (in + 7) / 8,
+                         [&](int r, int c) { return (r < od && c < in) ? Wl[(size_t)r * in + c] : 0.f; });
+    o_wb[l] = pack_stage(blob, 0, (in + 31) / 32, (od + 7) / 8,
+                         [&](int r, int c) { return (r < in && c < od) ? Wl[(size_t)c * in + r] : 0.f; });
+    o_b[l] = blob.alloc(HM_ANY_MAX_WIDTH);
+    for (int f = 0; f < od; ++f) blob.host[o_b[l] + f] = bias[l][f];
+    o_g[l] = o_be[l] = 0;
+    if (arch->layer_norm[l]) {
+      o_g[l] = blob.alloc(HM_ANY_MAX_WIDTH);
+      o_be[l] = blob.alloc(HM_ANY_MAX_WIDTH);
+      for (int f = 0; f < od; ++f) { blob.host[o_g[l] + f] = ln_weight[l][f]; blob.host[o_be[l] + f] = ln_bias[l][f]; }
+    }
+  }
+  hm_decoder_s* d = new hm_decoder_s();
+  d->L = L;
+  d->precision = 0;
+  d->generic = 1;
+  d->blob_bytes = blob.host.size() * sizeof(float);
+  hipError_t e = hipMalloc(&d->d_blob, d->blob_bytes);
+  if (e != hipSuccess) { hm_set_error("hipMalloc(%zu) failed: %s", d->blob_bytes, hipGetErrorString(e)); delete d; return -2; }
+  e = hipMemcpy(d->d_blob, blob.host.data(), d->blob_bytes, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMalloc(&d->d_any_slab, any_slab_bytes(n_ln));
+  if (e != hipSuccess) {
+    hm_set_error("device allocation / copy failed: %s", hipGetErrorString(e));
+    (void)hipFree(d->d_blob); delete d; return -2;
+  }
+  const float* base = static_cast<const float*>(d->d_blob);
+  AnyDev& av = d->any;
+  av.L = L; av.n_lin = n; av.use_tanh = arch->use_tanh ? 1 : 0; av.n_ln = n_ln;
+  for (int l = 0; l < n; ++l) {
+    AnyLayer& ly = av.lay[l];
+    ly.wf = base + o_wf[l]; ly.wb = base + o_wb[l]; ly.bias = base + o_b[l];
+    ly.gamma = arch->layer_norm[l] ? base + o_g[l] : nullptr;
+    ly.beta = arch->layer_norm[l] ? base + o_be[l] : nullptr;
+    ly.in_dim = arch->in_dim[l]; ly.out_dim = arch->out_dim[l]; ly.cat = arch->cat[l];
+    ly.ln = arch->layer_norm[l] ? 1 : 0;
+  }
+  *out = d;
+  return 0;
+}
+
 extern "C" int hm_decoder_destroy(hm_decoder_s* d) {
   if (d == nullptr) return 0;
   (void)hipFree(d->d_blob);
+  (void)hipFree(d->d_any_slab);
   delete d;
   return 0;
 }
@@ -214,6 +294,8 @@ extern "C" int hm_decoder_latent_dim(const hm_decoder_s* d) { return d ? d->L : 
 
 extern "C" int hm_decoder_set_precision(hm_decoder_s* d, int precision) {
   if (d == nullptr) { hm_set_error("null decoder"); return -1; }
+  if (d->generic && precision != 0) {
+    hm_set_error("a decoder built by hm_decoder_create_arch runs in exact fp32 (precision 0) only"); return -1; }
   if (precision < 0 || precision > 3) { hm_set_error("precision must be 0 (f32), 1 (f16x3), 2 (f16x3f_f16b) or 3 (f16)"); return -1; }
   d->precision = precision;
   return 0;

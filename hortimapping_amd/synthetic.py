@@ -264,3 +264,78 @@ def make_instance(Ws, bs, latent_dim, inst_id, n_pts=2048, n_frames=1, n_fg=32, 
         "z_true": z_true,
         "T_wo_true": T_wo_true.astype(np.float32),
     }
+
+
+# --------------------------------------------------------------------------------------
+# decoders of OTHER layer tables (any `Decoder(latent_size, dims, ...)` of deep_sdf_decoder.py:11-72)
+# --------------------------------------------------------------------------------------
+def arch_layer_dims(latent_dim, dims, latent_in=(), xyz_in_all=False):
+    """[(out, in)] of lin0..lin{n-1} as `Decoder.__init__` sizes them (deep_sdf_decoder.py:29-47)."""
+    full = [latent_dim + 3] + list(dims) + [1]
+    n = len(full)
+    shp = []
+    for layer in range(n - 1):
+        if layer + 1 in latent_in:
+            od = full[layer + 1] - full[0]
+        else:
+            od = full[layer + 1]
+            if xyz_in_all and layer != n - 2:
+                od -= 3
+        shp.append((od, full[layer]))
+    return shp
+
+
+def make_arch_decoder(latent_dim, dims, latent_in=(), norm_layers=(), weight_norm=False, xyz_in_all=False,
+                      use_tanh=False, seed=0, analytic=False, r0=0.04, aniso=(1.0, 0.75, 1.3), latent_gain=0.1,
+                      noise=0.01, freq_sigma=2.0):
+    """Parameters, in the reference's state-dict layout, of `Decoder(latent_dim, dims, norm_layers=..., latent_in=...,
+    weight_norm=..., xyz_in_all=..., use_tanh=...)`: `lin{l}.weight_v/_g` for weight-normed layers (`weight_norm` and l in
+    `norm_layers`, deep_sdf_decoder.py:49-54), `lin{l}.weight` otherwise, `lin{l}.bias`, and `bn{l}.weight/.bias` for the
+    LayerNorm modules of `norm_layers` without `weight_norm` (:57-62).  Plus 'latent_dim' and 'use_tanh'.
+
+    analytic=False: He-scaled random weights (the function is arbitrary; used for decode / Jacobian parity).
+    analytic=True (no LayerNorm): the "lumpy sphere" of `make_synthetic_decoder` realised in this layer table -- half-space
+    features in lin0, every later hidden layer passes the running mean on, `4 * mean - r0` at the end -- so that the LM
+    loop has a fruit to fit.  All draws come from np.random.RandomState(seed) in a fixed order."""
+    L = int(latent_dim)
+    rs = np.random.RandomState(seed)
+    shp = arch_layer_dims(L, dims, latent_in, xyz_in_all)
+    n = len(shp)
+    has_ln = [(not weight_norm) and (l in norm_layers) and l < n - 1 for l in range(n)]
+    if analytic and any(has_ln):
+        raise ValueError("the analytic construction needs a table without LayerNorm")
+    out = {"latent_dim": L, "use_tanh": bool(use_tanh)}
+    an = np.asarray(aniso, dtype=np.float64)
+    for l, (od, idim) in enumerate(shp):
+        if analytic:
+            if l == 0:
+                u = rs.randn(od, 3)
+                u /= np.linalg.norm(u, axis=1, keepdims=True)
+                omega = freq_sigma * rs.randn(L, 3)
+                psi = rs.uniform(0, 2 * np.pi, L)
+                w = np.concatenate([latent_gain / np.sqrt(L) * np.sqrt(2.0) * np.cos(u @ omega.T + psi), u * an], axis=1)
+            else:
+                prev = shp[l - 1][0]                      # the part of the input that is the previous layer's output
+                w = np.zeros((od, idim))
+                w[:, :prev] = (4.0 if l == n - 1 else 1.0) / prev
+                w += noise * rs.randn(od, idim) / idim
+            b = np.zeros(od)
+            if l == n - 1:
+                b[0] = -r0
+        else:
+            w = rs.randn(od, idim) * np.sqrt(2.0 / idim)
+            b = 0.1 * rs.randn(od)
+            if l == n - 1:
+                w *= 0.25
+        w = w.astype(np.float32)
+        if weight_norm and l in norm_layers:
+            g = np.linalg.norm(w.astype(np.float64), axis=1, keepdims=True) * (1.0 + 0.05 * rs.randn(od, 1))
+            out[f"lin{l}.weight_v"] = w
+            out[f"lin{l}.weight_g"] = g.astype(np.float32)
+        else:
+            out[f"lin{l}.weight"] = w
+        out[f"lin{l}.bias"] = b.astype(np.float32)
+        if has_ln[l]:
+            out[f"bn{l}.weight"] = (1.0 + 0.2 * rs.randn(od)).astype(np.float32)
+            out[f"bn{l}.bias"] = (0.1 * rs.randn(od)).astype(np.float32)
+    return out

@@ -51,6 +51,31 @@ int hm_decoder_create(int latent_dim, const float* const* W, const float* const*
 int hm_decoder_destroy(hm_decoder_t dec);
 int hm_decoder_latent_dim(hm_decoder_t dec);
 
+/* ---- decoder handle for ANY layer table the reference's `Decoder` class can build
+ * (deepsdf/networks/deep_sdf_decoder.py:11-72: `dims`, `latent_in`, `xyz_in_all`, `norm_layers` with or without
+ * `weight_norm`, `use_tanh`; dropout is the identity in eval mode, which is all the optimiser uses).  Layer l
+ * (0 <= l < n_lin) is Linear(in_dim[l], out_dim[l]); its input is the previous layer's output, with the network input
+ * [z | xyz] appended when cat[l] == 1 (l in latent_in, :87-88) or xyz appended when cat[l] == 2 (xyz_in_all, :89-90);
+ * hidden layers are followed by LayerNorm when layer_norm[l] (:96-101; eps 1e-5, affine) and ReLU; the last layer has
+ * one output, followed by tanh when use_tanh (:93-94) and always by the final tanh (:107-108).  W[l] / bias[l] are
+ * HOST pointers to the folded (weight-norm applied) row-major (out_dim[l], in_dim[l]) fp32 matrices; ln_weight[l] /
+ * ln_bias[l] (out_dim[l] floats) are read for layers with layer_norm[l] only (the arrays may be NULL without any).
+ * Limits: n_lin <= HM_MAX_LIN, every width <= 512, latent_dim as for hm_decoder_create.  Such a handle computes in
+ * exact fp32 on the matrix cores (hm_decoder_set_precision accepts 0 only) and is accepted by every entry point that
+ * takes an hm_decoder_t; the shipped 8 x 512 / latent_in = [4] models are faster through hm_decoder_create. */
+#define HM_MAX_LIN 16
+typedef struct hm_decoder_arch {
+  int latent_dim;
+  int n_lin;
+  int use_tanh;
+  int in_dim[HM_MAX_LIN];
+  int out_dim[HM_MAX_LIN];
+  int cat[HM_MAX_LIN];
+  int layer_norm[HM_MAX_LIN];
+} hm_decoder_arch;
+int hm_decoder_create_arch(const hm_decoder_arch* arch, const float* const* W, const float* const* bias,
+                           const float* const* ln_weight, const float* const* ln_bias, hm_decoder_t* out);
+
 /* Arithmetic of the decoder GEMMs (the reference computes in fp32, optimizer.py:19):
  *   0  exact fp32 on the f32-input matrix cores (v_mfma_f32_32x32x2_f32; bitwise an fmaf chain)   [default]
  *   1  "f16x3": fp16 matrix cores with hi/lo split operands, three MFMA passes into one fp32 accumulator,

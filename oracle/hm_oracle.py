@@ -41,25 +41,43 @@ VARIANT = set()
 # --------------------------------------------------------------------------------------
 @dataclass
 class FoldedDecoder:
-    """Effective weights after weight-norm folding (deep_sdf_decoder.py:49-54)."""
+    """Effective weights after weight-norm folding (deep_sdf_decoder.py:49-54) plus the layer table of
+    `Decoder.__init__` (:29-72).  `cat[l]`: what `forward` appends to layer l's input -- 1: the network input [z | xyz]
+    (l in `latent_in`, :87-88), 2: xyz (`xyz_in_all`, :89-90), 0: nothing; None = the shipped table (latent_in = [4]).
+    `ln[l]` = (weight, bias) of the `bn{l}` LayerNorm of `norm_layers` without `weight_norm` (:57-62, 96-101)."""
     Ws: List[torch.Tensor]
     bs: List[torch.Tensor]
     latent_dim: int
+    cat: Optional[List[int]] = None
+    ln: dict = field(default_factory=dict)
+    use_tanh: bool = False
 
     @property
     def dtype(self):
         return self.Ws[0].dtype
 
     def to(self, dtype):
-        return FoldedDecoder([w.to(dtype) for w in self.Ws], [b.to(dtype) for b in self.bs],
-                             self.latent_dim)
+        return FoldedDecoder([w.to(dtype) for w in self.Ws], [b.to(dtype) for b in self.bs], self.latent_dim, self.cat,
+                             {l: (g.to(dtype), b.to(dtype)) for l, (g, b) in self.ln.items()}, self.use_tanh)
+
+    def cat_table(self):
+        if self.cat is not None:
+            return self.cat
+        return [1 if l == SKIP_LAYER else 0 for l in range(len(self.Ws))]
 
 
 def fold_decoder(params, dtype=torch.float32) -> FoldedDecoder:
-    """`params`: dict with lin{l}.weight_v/weight_g/bias (l<8), lin8.weight/bias.
-    W_l = g_l * v_l / ||v_l||_row  (torch weight_norm, dim=0; deep_sdf_decoder.py:49-54)."""
-    Ws, bs = [], []
-    for l in range(N_LIN):
+    """`params`: dict with lin{l}.weight_v/weight_g (weight-normed layers) or lin{l}.weight, lin{l}.bias, optional
+    bn{l}.weight/bias, 'latent_dim', optional 'use_tanh'.
+    W_l = g_l * v_l / ||v_l||_row  (torch weight_norm, dim=0; deep_sdf_decoder.py:49-54).  The concatenation table is read
+    off the layer widths: Decoder.__init__ shrinks the previous layer by latent_dim + 3 before a `latent_in` layer (:41-42)
+    and by 3 before every other layer under `xyz_in_all` (:45-46)."""
+    Ws, bs, ln = [], [], {}
+    n = 0
+    while f"lin{n}.bias" in params:
+        n += 1
+    L = int(params["latent_dim"])
+    for l in range(n):
         if f"lin{l}.weight_v" in params:
             v = torch.as_tensor(np.asarray(params[f"lin{l}.weight_v"]), dtype=torch.float32)
             g = torch.as_tensor(np.asarray(params[f"lin{l}.weight_g"]), dtype=torch.float32).reshape(-1, 1)
@@ -68,7 +86,14 @@ def fold_decoder(params, dtype=torch.float32) -> FoldedDecoder:
             w = torch.as_tensor(np.asarray(params[f"lin{l}.weight"]), dtype=torch.float32)
         Ws.append(w.to(dtype).contiguous())
         bs.append(torch.as_tensor(np.asarray(params[f"lin{l}.bias"]), dtype=torch.float32).to(dtype))
-    return FoldedDecoder(Ws, bs, int(params["latent_dim"]))
+        if f"bn{l}.weight" in params and l < n - 1:             # :96 the last layer's bn is never applied
+            ln[l] = (torch.as_tensor(np.asarray(params[f"bn{l}.weight"]), dtype=torch.float32).to(dtype),
+                     torch.as_tensor(np.asarray(params[f"bn{l}.bias"]), dtype=torch.float32).to(dtype))
+    cat = [0]
+    for l in range(1, n):
+        extra = Ws[l].shape[1] - Ws[l - 1].shape[0]
+        cat.append({0: 0, L + 3: 1, 3: 2}[extra])
+    return FoldedDecoder(Ws, bs, L, cat, ln, bool(params.get("use_tanh", False)))
 
 
 def _inputs(dec: FoldedDecoder, z, x):
@@ -77,17 +102,45 @@ def _inputs(dec: FoldedDecoder, z, x):
     return torch.cat([z.expand(x.shape[0], -1), x], dim=1)  # latent first, xyz last (utils.py:165,185)
 
 
+LN_EPS = 1e-5     # nn.LayerNorm default (deep_sdf_decoder.py:62)
+
+
+def _layers(dec: FoldedDecoder, u, keep: bool):
+    """Decoder.forward (deep_sdf_decoder.py:75-110) in eval mode (dropout inert).  Returns the pre-tanh output (n,), the
+    inner tanh value when `use_tanh` (else None) and, with keep=True, per hidden layer (ReLU mask, x_hat, rstd)."""
+    n = len(dec.Ws)
+    cat = dec.cat_table()
+    h = u
+    saved = []
+    for l in range(n):
+        if cat[l] == 1:
+            h = torch.cat([h, u], dim=1)                    # :87-88
+        elif cat[l] == 2:
+            h = torch.cat([h, u[:, -3:]], dim=1)            # :89-90
+        a = h @ dec.Ws[l].T + dec.bs[l]                     # :91
+        if l < n - 1:
+            xh = rstd = None
+            if l in dec.ln:                                 # :96-101 bn = nn.LayerNorm(out_dim)
+                mu = a.mean(dim=1, keepdim=True)
+                var = ((a - mu) ** 2).mean(dim=1, keepdim=True)
+                rstd = 1.0 / torch.sqrt(var + LN_EPS)
+                xh = (a - mu) * rstd
+                a = xh * dec.ln[l][0] + dec.ln[l][1]
+            mk = a > 0
+            h = a * mk                                      # :102 relu
+            if keep:
+                saved.append((mk, xh, rstd))
+        else:
+            h = a
+    pre = h[:, 0]
+    t = torch.tanh(pre) if dec.use_tanh else None           # :93-94
+    return pre, t, saved
+
+
 def decoder_forward(dec: FoldedDecoder, z, x):
     """sdf values (n,) -- Decoder.forward (deep_sdf_decoder.py:75-110) via decode_sdf (utils.py:144-172)."""
-    u = _inputs(dec, z, x)
-    h = u
-    for l in range(N_LIN):
-        if l == SKIP_LAYER:
-            h = torch.cat([h, u], dim=1)                    # deep_sdf_decoder.py:87-88
-        h = h @ dec.Ws[l].T + dec.bs[l]
-        if l < N_LIN - 1:
-            h = torch.relu(h)                               # :95-103 (dropout inert in eval)
-    return torch.tanh(h[:, 0])                              # :107-108
+    pre, t, _ = _layers(dec, _inputs(dec, z, x), False)
+    return torch.tanh(t if t is not None else pre)          # :107-108
 
 
 def decoder_jacobian(dec: FoldedDecoder, z, x):
@@ -101,27 +154,30 @@ def decoder_jacobian(dec: FoldedDecoder, z, x):
             VARIANT.add("jac64")
         return y64.float(), g64.float()
     u = _inputs(dec, z, x)
-    h = u
-    masks = []
-    for l in range(N_LIN):
-        if l == SKIP_LAYER:
-            h = torch.cat([h, u], dim=1)
-        a = h @ dec.Ws[l].T + dec.bs[l]
-        if l < N_LIN - 1:
-            mk = a > 0
-            masks.append(mk)
-            h = a * mk
-        else:
-            h = a
-    y = torch.tanh(h[:, 0])
-    G = (1.0 - y * y)[:, None] * dec.Ws[8]                  # (n, 512)
+    n = len(dec.Ws)
+    cat = dec.cat_table()
+    D0 = u.shape[1]
+    pre, t, saved = _layers(dec, u, True)
+    y = torch.tanh(t if t is not None else pre)
+    dy = 1.0 - y * y
+    if t is not None:
+        dy = dy * (1.0 - t * t)
+    G = dy[:, None] * dec.Ws[n - 1]                         # gradient w.r.t. the last layer's input
     g_u = torch.zeros_like(u)
-    m = dec.Ws[3].shape[0]
-    for l in range(N_LIN - 2, -1, -1):
-        G = (G * masks[l]) @ dec.Ws[l]
-        if l == SKIP_LAYER:
-            g_u = g_u + G[:, m:]
-            G = G[:, :m]
+    for l in range(n - 1, 0, -1):
+        # G: gradient w.r.t. layer l's (concatenated) input; split off what was appended, the rest belongs to layer l - 1
+        if cat[l] == 1:
+            g_u = g_u + G[:, -D0:]
+            G = G[:, :-D0]
+        elif cat[l] == 2:
+            g_u[:, -3:] = g_u[:, -3:] + G[:, -3:]
+            G = G[:, :-3]
+        mk, xh, rstd = saved[l - 1]
+        G = G * mk
+        if xh is not None:                                  # LayerNorm backward
+            gg = G * dec.ln[l - 1][0]
+            G = rstd * (gg - gg.mean(dim=1, keepdim=True) - xh * (gg * xh).mean(dim=1, keepdim=True))
+        G = G @ dec.Ws[l - 1]
     g_u = g_u + G
     return y, g_u
 

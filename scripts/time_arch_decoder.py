@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""Timing of the any-architecture decoder kernel (csrc/hm_decoder_any.hip) next to the specialised exact-f32 kernel on
+the SHIPPED layer table (same weights, same queries), plus a few other tables.  GPU box:  python scripts/time_arch_decoder.py"""
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from hortimapping_amd import ops, synthetic as S                     # noqa: E402
+from hortimapping_amd.decoder import DecoderWeights                   # noqa: E402
+
+
+def flops_per_query(table, mode):
+    f = sum(2 * i * o for i, o in zip(table["in_dim"], table["out_dim"]))
+    return f * (2 if mode == 1 else 1)
+
+
+def timeit(dec, B, n, mode, reps=5):
+    L = dec.latent_dim
+    lat = (0.07 * torch.randn(B, L)).cuda()
+    pts4 = torch.zeros(B, n, 4)
+    pts4[..., :3] = 0.04 * torch.randn(B, n, 3)
+    pts4 = pts4.cuda()
+    nq = torch.full((B,), n, dtype=torch.int32).cuda()
+    ops.decode_batch(dec, lat, pts4, nq, mode=mode, pose_dim=7)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        ops.decode_batch(dec, lat, pts4, nq, mode=mode, pose_dim=7)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps
+
+
+def main():
+    os.environ.pop("HM_PRECISION", None)
+    B, n = 64, 1024
+    p = S.make_synthetic_decoder(256, seed=2)
+    rows = []
+    for label, dec in (("shipped table, specialised f32 kernel", DecoderWeights.from_params(p)),
+                       ("shipped table, any-architecture kernel", DecoderWeights.from_params(p, force_generic=True))):
+        for mode in (0, 1):
+            t = timeit(dec, B, n, mode)
+            rows.append((label, mode, t, flops_per_query(dec.table, mode) * B * n / t / 1e12))
+    for label, kw in (("4 x 256, latent_in [2], weight norm", dict(latent_dim=64, dims=[256] * 4, latent_in=[2], norm_layers=[0, 1, 2, 3], weight_norm=True)),
+                      ("8 x 512, latent_in [4], LayerNorm", dict(latent_dim=256, dims=[512] * 8, latent_in=[4], norm_layers=list(range(8)), weight_norm=False)),
+                      ("6 x 128 plain", dict(latent_dim=32, dims=[128] * 6))):
+        dec = DecoderWeights.from_params(S.make_arch_decoder(seed=1, **kw))
+        for mode in (0, 1):
+            t = timeit(dec, B, n, mode)
+            rows.append((label, mode, t, flops_per_query(dec.table, mode) * B * n / t / 1e12))
+    print("decode API, %d instances x %d queries (pose_dim 7); TFLOP/s on the dense layer-table flop" % (B, n))
+    for label, mode, t, tf in rows:
+        print("%-42s %-8s %8.3f ms  %7.1f TFLOP/s" % (label, "fwd" if mode == 0 else "fwd+bwd", t * 1e3, tf))
+
+
+if __name__ == "__main__":
+    main()

@@ -14,6 +14,22 @@ DEC_SPECS = {
 }
 
 
+# kwargs of hortimapping_amd.synthetic.make_arch_decoder for the g17 fixtures: layer tables OTHER than the shipped one
+# (deep_sdf_decoder.py:11-72: dims / latent_in / xyz_in_all / norm_layers with and without weight_norm / use_tanh)
+ARCH_SPECS = {
+    "plain": dict(latent_dim=32, dims=[64, 64, 64], seed=11),
+    "skip_wn": dict(latent_dim=32, dims=[128] * 4, latent_in=[2], norm_layers=[0, 1, 2, 3], weight_norm=True, seed=12),
+    "xyz_all": dict(latent_dim=32, dims=[96] * 4, latent_in=[2], norm_layers=[0, 1, 2, 3], weight_norm=True,
+                    xyz_in_all=True, seed=13),
+    "layernorm": dict(latent_dim=32, dims=[128, 160, 128], latent_in=[2], norm_layers=[0, 1, 2, 3], weight_norm=False,
+                      seed=14),
+    "tanh_wide": dict(latent_dim=32, dims=[512, 256, 512, 300], latent_in=[1, 3], norm_layers=[0, 2], weight_norm=True,
+                      use_tanh=True, seed=15),
+    "deep_ln64": dict(latent_dim=64, dims=[72] * 14, latent_in=[7], norm_layers=[1, 5, 9], weight_norm=False,
+                      xyz_in_all=True, seed=16),
+}
+
+
 def load(name):
     return np.load(os.path.join(GOLDEN_DIR, name + ".npz"), allow_pickle=False)
 

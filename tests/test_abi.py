@@ -42,8 +42,9 @@ def test_library_exports_every_declared_symbol():
 
 def test_ctypes_structs_match_c_layout():
     """Compile a tiny C program against the public header and compare sizeof/offsetof with the ctypes mirrors."""
-    from hortimapping_amd import optimizer as HO
+    from hortimapping_amd import decoder as HD, optimizer as HO
     fields = {
+        "hm_decoder_arch": (HD.HmDecoderArch, ["latent_dim", "use_tanh", "in_dim", "out_dim", "cat", "layer_norm"]),
         "hm_opt_cfg": (HO.HmOptCfg, ["scale_on", "lm_lambda_0", "n_sample_on_ray", "w_codereg", "max_iter",
                                      "epsilon_s", "min_grad_thre"]),
         "hm_limits": (HO.HmLimits, ["max_batch", "max_grad_samples"]),

@@ -1,0 +1,229 @@
+"""Decoders of OTHER layer tables than the shipped one on the HIP path (`hm_decoder_create_arch`,
+csrc/hm_decoder_any.hip): decode / Jacobian parity against the g17 fixtures captured from the reference's `Decoder`
+class and against the fp64 oracle, and the exact-fp32 LM loops (`hm_optimize_batch`) on such a decoder against the
+CPU oracle's loops."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests.golden_util import ARCH_SPECS, load, relmax
+
+pytestmark = pytest.mark.gpu
+
+
+def arch_params(name):
+    from hortimapping_amd import synthetic as S
+    return S.make_arch_decoder(**dict(ARCH_SPECS[name]))
+
+
+@pytest.fixture(autouse=True)
+def _no_process_default(monkeypatch):
+    monkeypatch.delenv("HM_PRECISION", raising=False)
+
+
+@pytest.mark.parametrize("name", sorted(ARCH_SPECS))
+def test_g17_decode_and_jacobian_vs_the_reference_class(name):
+    """decode_sdf / get_batch_sdf_jacobian (utils.py:144-193) on layer tables the fixed-architecture kernels refuse."""
+    from hortimapping_amd import utils as U
+    from hortimapping_amd.decoder import DecoderWeights
+    g = load(f"g17_arch_{name}")
+    dec = DecoderWeights.from_params(arch_params(name))
+    assert dec.generic and dec.precision == "f32"
+    z, x = torch.from_numpy(g["z"]), torch.from_numpy(g["x"])
+    assert relmax(U.decode_sdf(dec, z, x).cpu(), g["sdf"]) < 5e-6
+    y, jac = U.get_batch_sdf_jacobian(dec, z, x)
+    assert y.shape == (70, 1, 1) and jac.shape == (70, 1, g["g"].shape[1])
+    assert relmax(y.cpu().reshape(-1), g["y"]) < 5e-6
+    assert relmax(jac.cpu()[:, 0], g["g"]) < 2e-5
+
+
+@pytest.mark.parametrize("name", ["skip_wn", "layernorm", "tanh_wide", "deep_ln64"])
+def test_arch_decoder_vs_fp64_oracle_ragged(name):
+    """Ragged per-instance counts (tails, an empty instance, more tiles than one pass), all three pose layouts."""
+    from hortimapping_amd import ops
+    from hortimapping_amd.decoder import DecoderWeights
+    from oracle import hm_oracle as O
+    p = arch_params(name)
+    L = int(p["latent_dim"])
+    dec = DecoderWeights.from_params(p)
+    od = O.fold_decoder(p).to(torch.float64)
+    gen = torch.Generator().manual_seed(L + len(name))
+    nq = [1, 63, 64, 65, 200, 0]
+    B = len(nq)
+    lat = 0.3 * torch.randn(B, L, generator=gen)
+    pts = 0.3 * torch.randn(B, 256, 3, generator=gen)
+    pts4 = torch.zeros(B, 256, 4)
+    pts4[..., :3] = pts
+    for pose_dim in (0, 6, 7):
+        y, J = ops.decode_batch(dec, lat.cuda(), pts4.cuda(), torch.tensor(nq, dtype=torch.int32).cuda(), mode=1,
+                                pose_dim=pose_dim)
+        y0, _ = ops.decode_batch(dec, lat.cuda(), pts4.cuda(), torch.tensor(nq, dtype=torch.int32).cuda(), mode=0)
+        assert torch.equal(y, y0)                                        # forward-only launch: same bits
+        y, J = y.cpu(), J.cpu()
+        for b, k in enumerate(nq):
+            if k == 0:
+                assert float(J[b].abs().max()) == 0.0 and float(y[b].abs().max()) == 0.0
+                continue
+            yo, go = O.decoder_jacobian(od, lat[b], pts[b, :k])
+            assert relmax(y[b, :k], yo) < 5e-6
+            assert relmax(J[b, :k, :L], go[:, :L]) < 2e-5
+            assert relmax(J[b, :k, L + 7], yo) < 5e-6                    # residual column of the extended row
+            if pose_dim == 0:
+                ref = go[:, L:]
+            else:
+                ref = torch.einsum("ni,nip->np", go[:, L:], O.pose_jacobian(pts[b, :k].double(), pose_dim == 7))
+            assert relmax(J[b, :k, L:L + ref.shape[1]], ref) < 2e-5
+            assert float(J[b, k:].abs().max()) == 0.0                    # rows beyond n_q untouched
+
+
+def test_arch_decoder_many_tiles_equal_single_tiles():
+    """More tiles than persistent workgroups (grid-stride loop, LayerNorm slab reuse): bits equal a small launch's."""
+    from hortimapping_amd import ops
+    from hortimapping_amd.decoder import DecoderWeights
+    dec = DecoderWeights.from_params(arch_params("layernorm"))
+    gen = torch.Generator().manual_seed(3)
+    B, n = 40, 1024                                                     # 640 tiles > 512 workgroups
+    lat = (0.3 * torch.randn(B, 32, generator=gen)).cuda()
+    pts4 = torch.zeros(B, n, 4)
+    pts4[..., :3] = 0.3 * torch.randn(B, n, 3, generator=gen)
+    pts4 = pts4.cuda()
+    nq = torch.full((B,), n, dtype=torch.int32).cuda()
+    y, J = ops.decode_batch(dec, lat, pts4, nq, mode=1, pose_dim=7)
+    for b in (0, 17, 39):
+        y1, J1 = ops.decode_batch(dec, lat[b:b + 1].contiguous(), pts4[b:b + 1, 448:512].contiguous(),
+                                  torch.tensor([64], dtype=torch.int32).cuda(), mode=1, pose_dim=7)
+        assert torch.equal(y[b, 448:512], y1[0]) and torch.equal(J[b, 448:512], J1[0])
+
+
+def test_arch_decoder_is_f32_only_and_entry_points_keep_it_there():
+    from hortimapping_amd.decoder import DecoderWeights
+    dec = DecoderWeights.from_params(arch_params("plain"))
+    for name in ("f16x3", "f16x3f_f16b", "f16"):
+        with pytest.raises(RuntimeError, match="exact fp32"):
+            dec.set_precision(name)
+    assert dec.precision == "f32" and dec.f32_twin() is dec
+    dec.set_precision("f32")
+
+
+class _MiniDecoder(torch.nn.Module):
+    """A module with the reference class's attribute names and state-dict keys (what `from_module` reads); the reference
+    class itself does not exist on the GPU box."""
+
+    def __init__(self, params, weight_norm, use_tanh):
+        super().__init__()
+        self.weight_norm, self.use_tanh = weight_norm, use_tanh
+        for k, v in params.items():
+            if k in ("latent_dim", "use_tanh"):
+                continue
+            mod, _, leaf = k.partition(".")
+            if not hasattr(self, mod):
+                setattr(self, mod, torch.nn.Module())
+            getattr(self, mod).register_parameter(leaf, torch.nn.Parameter(torch.from_numpy(np.asarray(v).copy())))
+
+
+def _analytic_arch(L=32):
+    from hortimapping_amd import synthetic as S
+    return S.make_arch_decoder(L, [128] * 4, latent_in=[2], norm_layers=[0, 1, 2, 3], weight_norm=True, seed=21,
+                               analytic=True)
+
+
+def _instances(p, ids, **kw):
+    from hortimapping_amd import synthetic as S
+    from oracle import hm_oracle as O
+    od64 = O.fold_decoder(p).to(torch.float64)
+
+    def factory(z):
+        zt = torch.from_numpy(np.asarray(z, dtype=np.float64))
+        return lambda pts: O.decoder_forward(od64, zt, torch.from_numpy(np.asarray(pts, dtype=np.float64))).numpy()
+    return [S.make_instance(None, None, int(p["latent_dim"]), i, sdf_fn_factory=factory, **kw) for i in ids]
+
+
+@pytest.mark.parametrize("pose_known", [True, False])
+def test_joint_lm_loop_on_another_layer_table_vs_oracle(pose_known):
+    """shape_pose_joint_opt (optimizer.py:28-302) with a 4 x 128 / latent_in = [2] decoder: iteration counts equal, state
+    at the tolerance of the fixed-architecture f32 trajectory tests."""
+    from hortimapping_amd import optimizer as HO, workloads as W
+    from hortimapping_amd.decoder import DecoderWeights
+    from oracle import hm_oracle as O
+    p = _analytic_arch()
+    dec = DecoderWeights.from_module(_MiniDecoder(p, True, False))
+    assert dec.generic
+    od = O.fold_decoder(p)
+    cfg = W.c2_opt_cfg(max_iter=4, n_sample_on_ray=16, n_frame=1)
+    dicts = _instances(p, (0, 1, 2), n_pts=192, n_frames=1, n_fg=48, n_bg=48)
+    res = HO.optimize_batch(dec, cfg, [W.to_instance(d, pose_known=pose_known) for d in dicts])
+    for d, r in zip(dicts, res):
+        rd = {k: [torch.from_numpy(a) for a in v] for k, v in d["render"].items()}
+        z, T, n = O.shape_pose_joint_opt(od, cfg, torch.from_numpy(d["latent0"]), torch.from_numpy(d["T_ow0"]), rd,
+                                         torch.from_numpy(d["points_w"]), d["cube_radius"], pose_known=pose_known)
+        assert r.iter_count == n == 4, (r.iter_count, n, r.status)
+        assert relmax(r.latent, z) < 1e-3 and relmax(r.T_ow, T) < 1e-4
+        assert float(z.abs().max()) > 1e-3                             # the latent did move
+
+
+def test_shape_only_loop_with_layernorm_decoder_vs_oracle():
+    """shape_opt_deepsdf (optimizer.py:306-429) through the drop-in class on a LayerNorm decoder."""
+    from hortimapping_amd import optimizer as HO, workloads as W
+    from oracle import hm_oracle as O
+    p = arch_params("layernorm")
+    od = O.fold_decoder(p)
+    cfg = {"device": "cuda", "opt": W.c2_opt_cfg(max_iter=3)}
+    opt = HO.Optimizer(cfg, _MiniDecoder(p, False, False), None, None)
+    assert opt.decoder.generic and opt.decoder.precision == "f32" and sorted(opt.decoder.ln) == [0, 1, 2]
+    gen = torch.Generator().manual_seed(9)
+    pts = 0.05 * torch.randn(300, 3, generator=gen) + torch.tensor([0.0, 0.0, 0.5])
+    T_ow = torch.eye(4)
+    T_ow[:3, 3] = torch.tensor([0.0, 0.0, -0.5])
+    lat = torch.zeros(32)
+    z, _, n = O.shape_opt_deepsdf(od, cfg["opt"], lat.clone(), T_ow, pts)
+    zg, _, ng = opt.shape_opt_deepsdf(lat.clone(), T_ow, pts)
+    assert ng == n == 3
+    assert relmax(zg.cpu(), z) < 1e-3 and float(z.abs().max()) > 1e-4
+
+
+def test_config_decoder_reads_other_specs(tmp_path):
+    """config_decoder (deepsdf/deep_sdf/workspace.py:203-225) with a specs.json that is not the shipped one."""
+    from hortimapping_amd import utils as U
+    from hortimapping_amd.decoder import config_decoder
+    name = "tanh_wide"
+    spec, p = ARCH_SPECS[name], arch_params(name)
+    d = str(tmp_path)
+    os.makedirs(os.path.join(d, "ModelParameters"))
+    ns = {"dims": spec["dims"], "dropout": [0, 1, 2, 3], "dropout_prob": 0.2, "norm_layers": spec["norm_layers"],
+          "latent_in": spec["latent_in"], "xyz_in_all": False, "use_tanh": True, "latent_dropout": False,
+          "weight_norm": True}
+    json.dump({"NetworkArch": "deep_sdf_decoder", "CodeLength": 32, "NetworkSpecs": ns}, open(os.path.join(d, "specs.json"), "w"))
+    sd = {"module." + k: torch.from_numpy(np.asarray(v).copy()) for k, v in p.items() if k not in ("latent_dim", "use_tanh")}
+    torch.save({"epoch": 1, "model_state_dict": sd}, os.path.join(d, "ModelParameters", "latest.pth"))
+    dec = config_decoder(d)
+    assert dec.generic and dec.use_tanh
+    g = load(f"g17_arch_{name}")
+    assert relmax(U.decode_sdf(dec, torch.from_numpy(g["z"]), torch.from_numpy(g["x"])).cpu(), g["sdf"]) < 5e-6
+    ns["latent_in"] = [1]                                               # specs that do not describe the checkpoint
+    json.dump({"NetworkArch": "deep_sdf_decoder", "CodeLength": 32, "NetworkSpecs": ns}, open(os.path.join(d, "specs.json"), "w"))
+    with pytest.raises(ValueError, match="does not match specs.json"):
+        config_decoder(d)
+
+
+@pytest.mark.parametrize("name", ["pepper32", "pepper256"])
+def test_shipped_table_on_the_any_architecture_kernel(name):
+    """The shipped 8 x 512 / latent_in = [4] table forced through hm_decoder_create_arch: G12 (the reference's outputs)
+    at the tolerances of the specialised exact-f32 kernel, and agreement with that kernel."""
+    from hortimapping_amd import utils as U
+    from hortimapping_amd.decoder import DecoderWeights
+    from tests.golden_util import decoder_params
+    g = load(f"g12_decoder_{name}")
+    p = decoder_params(name)
+    gen_dec = DecoderWeights.from_params(p, force_generic=True)
+    fix_dec = DecoderWeights.from_params(p)
+    assert gen_dec.generic and not fix_dec.generic
+    z, x = torch.from_numpy(g["z"]), torch.from_numpy(g["x"])
+    assert relmax(U.decode_sdf(gen_dec, z, x).cpu(), g["sdf"]) < 5e-6
+    y, jac = U.get_batch_sdf_jacobian(gen_dec, z, x)
+    assert relmax(y.cpu().reshape(-1), g["y"]) < 5e-6
+    assert relmax(jac.cpu()[:, 0], g["g"]) < 1e-5
+    y2, jac2 = U.get_batch_sdf_jacobian(fix_dec, z, x)
+    assert relmax(y.cpu(), y2.cpu()) < 2e-6 and relmax(jac.cpu(), jac2.cpu()) < 5e-6
