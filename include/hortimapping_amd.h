@@ -46,7 +46,8 @@ const char* hm_last_error(void);
 /* ---- decoder handle: replaces config_decoder (deepsdf/deep_sdf/workspace.py:203-225) + Decoder.__init__
  * (deepsdf/networks/deep_sdf_decoder.py:11-72).  W[l], bias[l] (l = 0..8) are HOST pointers to the folded
  * (weight-norm applied) row-major fp32 matrices: W0 (512, L+3), W1..2 (512,512), W3 (509-L, 512), W4..7 (512,512),
- * W8 (1,512).  Only the shipped architecture (8 x 512, latent_in=[4]) with L a multiple of 32, 32 <= L <= 256. */
+ * W8 (1,512).  Only the shipped architecture (8 x 512, latent_in=[4]) with L a multiple of 32, 32 <= L <= 256; every
+ * other layer table goes through hm_decoder_create_arch below. */
 int hm_decoder_create(int latent_dim, const float* const* W, const float* const* bias, hm_decoder_t* out);
 int hm_decoder_destroy(hm_decoder_t dec);
 int hm_decoder_latent_dim(hm_decoder_t dec);

@@ -17,20 +17,26 @@ def flops_per_query(table, mode):
     return f * (2 if mode == 1 else 1)
 
 
-def timeit(dec, B, n, mode, reps=5):
+def timeit(dec, B, n, mode, reps=20):
     L = dec.latent_dim
     lat = (0.07 * torch.randn(B, L)).cuda()
     pts4 = torch.zeros(B, n, 4)
     pts4[..., :3] = 0.04 * torch.randn(B, n, 3)
     pts4 = pts4.cuda()
     nq = torch.full((B,), n, dtype=torch.int32).cuda()
-    ops.decode_batch(dec, lat, pts4, nq, mode=mode, pose_dim=7)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(reps):
+    for _ in range(3):
         ops.decode_batch(dec, lat, pts4, nq, mode=mode, pose_dim=7)
     torch.cuda.synchronize()
-    return (time.perf_counter() - t0) / reps
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    t0 = time.perf_counter()
+    for a, b in ev:
+        a.record()
+        ops.decode_batch(dec, lat, pts4, nq, mode=mode, pose_dim=7)
+        b.record()
+    torch.cuda.synchronize()
+    wall = (time.perf_counter() - t0) / reps
+    dev = sorted(a.elapsed_time(b) * 1e-3 for a, b in ev)
+    return dev[len(dev) // 2], wall, dev[0], dev[-1]
 
 
 def main():
@@ -41,18 +47,20 @@ def main():
     for label, dec in (("shipped table, specialised f32 kernel", DecoderWeights.from_params(p)),
                        ("shipped table, any-architecture kernel", DecoderWeights.from_params(p, force_generic=True))):
         for mode in (0, 1):
-            t = timeit(dec, B, n, mode)
-            rows.append((label, mode, t, flops_per_query(dec.table, mode) * B * n / t / 1e12))
+            t, wall, lo, hi = timeit(dec, B, n, mode)
+            rows.append((label, mode, t, flops_per_query(dec.table, mode) * B * n / t / 1e12, wall, lo, hi))
     for label, kw in (("4 x 256, latent_in [2], weight norm", dict(latent_dim=64, dims=[256] * 4, latent_in=[2], norm_layers=[0, 1, 2, 3], weight_norm=True)),
                       ("8 x 512, latent_in [4], LayerNorm", dict(latent_dim=256, dims=[512] * 8, latent_in=[4], norm_layers=list(range(8)), weight_norm=False)),
                       ("6 x 128 plain", dict(latent_dim=32, dims=[128] * 6))):
         dec = DecoderWeights.from_params(S.make_arch_decoder(seed=1, **kw))
         for mode in (0, 1):
-            t = timeit(dec, B, n, mode)
-            rows.append((label, mode, t, flops_per_query(dec.table, mode) * B * n / t / 1e12))
+            t, wall, lo, hi = timeit(dec, B, n, mode)
+            rows.append((label, mode, t, flops_per_query(dec.table, mode) * B * n / t / 1e12, wall, lo, hi))
     print("decode API, %d instances x %d queries (pose_dim 7); TFLOP/s on the dense layer-table flop" % (B, n))
-    for label, mode, t, tf in rows:
-        print("%-42s %-8s %8.3f ms  %7.1f TFLOP/s" % (label, "fwd" if mode == 0 else "fwd+bwd", t * 1e3, tf))
+    print("(median of 20 calls by device events, memset of the output buffers included; [min .. max]; host wall per call)")
+    for label, mode, t, tf, wall, lo, hi in rows:
+        print("%-42s %-8s %8.3f ms  %7.1f TFLOP/s   [%.3f .. %.3f]  wall %.3f" %
+              (label, "fwd" if mode == 0 else "fwd+bwd", t * 1e3, tf, lo * 1e3, hi * 1e3, wall * 1e3))
 
 
 if __name__ == "__main__":
