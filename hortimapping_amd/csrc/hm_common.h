@@ -70,6 +70,11 @@ struct AnyLayer {
   const float* bias;   // [512], zero padded
   const float* gamma;  // [512] LayerNorm weight (layers with ln), zero padded
   const float* beta;   // [512] LayerNorm bias
+  // f16x3 copies (pack_stage_h: fp16 hi / lo planes at a per-operand power-of-two scale, K padded to steps of 16)
+  const void* wfh;     // forward A operand
+  const void* wbh;     // backward A operand
+  int kf16, kb16;      // K steps of 16: ceil(in_dim / 16), ceil(out_dim / 16)
+  float usf, usb;      // 2^-shift of the two operands: accumulators hold 2^shift * (W X)
   int in_dim, out_dim;
   int cat;             // input of this layer: 0 = previous output, 1 = cat[., z, xyz] (latent_in), 2 = cat[., xyz] (xyz_in_all)
   int ln;              // LayerNorm between this Linear and its ReLU
@@ -90,7 +95,7 @@ struct hm_decoder_s {
   void* d_blob;        // one allocation holding every packed array
   size_t blob_bytes;
   int L;
-  int generic;         // 1: built by hm_decoder_create_arch: `any` is valid, `dev` is not; exact fp32 only
+  int generic;         // 1: built by hm_decoder_create_arch: `any` is valid, `dev` is not; precisions 0 (exact fp32) and 1 (f16x3)
   hm::AnyDev any;
   void* d_any_slab;    // per-workgroup scratch of the any-architecture kernel (LayerNorm saves + d sdf / d z block)
 };

@@ -56,7 +56,9 @@ struct hm_workspace_s {
   bool have_fork;                 // ev_fork exists
   int groups_override;
   int host_pacing;                // 1: stay <= LAG + 1 iterations ahead of the device when early exits are possible
-  int k4_split;                   // f16x3 arithmetics: 0 fp32-input kernel, 1 K4h (tiles; default), 2 K4w (experimental builds only, else = 1)
+  int k4_split;                   // f16x3 arithmetics: 0 fp32-input kernel (default), 1 K4h (opt-in: +1.7 %, but its 1e-7 ... 7e-7 difference in H / b
+                                  // moves a Jacobian-sample count of tests/test_gpu_configs.py::test_frame_turns_invalid_mid_trajectory_L256 off the
+                                  // oracle's at iteration 8), 2 K4w (experimental builds only, else = 1)
   // test / A-B switches, scoped to THIS workspace: the override set by hm_workspace_set_debug (-1 = follow the process
   // default of hm_debug_split_render / hm_debug_force_direct_solve) and the value snapshotted when an entry point is
   // called -- one call never sees a switch change under it (a mask-less forward paired with a mask-reading backward)
@@ -359,6 +361,7 @@ namespace {
 // entry-point prologue: snapshot the switches, make sure the mask buffer exists when the fused path will run
 int begin_call(hm_workspace_s* ws, int joint) {
   ws->split_render = ws->dbg_split_override >= 0 ? ws->dbg_split_override : g_split_render;
+  if (ws->dec->generic) ws->split_render = 1;     // any-architecture decoders: separate launches through launch_decoder (no job lists, no saved masks)
   ws->force_direct = ws->dbg_direct_override >= 0 ? ws->dbg_direct_override : g_force_direct;
   if (joint && fused_path(ws) && ws->d_maskR == nullptr) {
     ws->maskR_bytes = (size_t)ws->lim.max_batch * (ws->nR_stride / TQ) * 8 * 512 * sizeof(unsigned long long);
@@ -398,7 +401,7 @@ extern "C" int hm_workspace_create(hm_decoder_s* dec, const hm_limits* lim, hm_w
   w->nR_stride = round_up(w->nray * w->lim.max_samples, TQ);
   const int cap = lim->max_grad_samples > 0 ? lim->max_grad_samples : w->nray * w->lim.max_samples;
   w->nG_stride = round_up(cap, TQ);
-  w->n_gres = 0; w->have_fork = false; w->groups_override = 0; w->host_pacing = 1; w->k4_split = 1;
+  w->n_gres = 0; w->have_fork = false; w->groups_override = 0; w->host_pacing = 1; w->k4_split = 0;
   Carver size_pass;
   carve(w, size_pass);
   w->blob_bytes = size_pass.off + 256;

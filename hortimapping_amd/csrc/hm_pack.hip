@@ -237,14 +237,19 @@ extern "C" int hm_decoder_create_arch(const hm_decoder_arch* arch, const float* 
   if (arch->out_dim[n - 1] != 1) { hm_set_error("the last layer must have one output (sdf)"); return -1; }
 
   Blob blob;
+  std::vector<uint16_t> hblob;
   size_t o_wf[HM_ANY_MAX_LIN], o_wb[HM_ANY_MAX_LIN], o_b[HM_ANY_MAX_LIN], o_g[HM_ANY_MAX_LIN], o_be[HM_ANY_MAX_LIN];
+  size_t h_wf[HM_ANY_MAX_LIN], h_wb[HM_ANY_MAX_LIN];
+  float usf[HM_ANY_MAX_LIN], usb[HM_ANY_MAX_LIN];
   for (int l = 0; l < n; ++l) {
     const int in = arch->in_dim[l], od = arch->out_dim[l];
     const float* Wl = W[l];
-    o_wf[l] = pack_stage(blob, 0, (od + 31) / 32, (in + 7) / 8,
-                         [&](int r, int c) { return (r < od && c < in) ? Wl[(size_t)r * in + c] : 0.f; });
-    o_wb[l] = pack_stage(blob, 0, (in + 31) / 32, (od + 7) / 8,
-                         [&](int r, int c) { return (r < in && c < od) ? Wl[(size_t)c * in + r] : 0.f; });
+    const std::function<float(int, int)> Af = [&](int r, int c) { return (r < od && c < in) ? Wl[(size_t)r * in + c] : 0.f; };
+    const std::function<float(int, int)> Ab = [&](int r, int c) { return (r < in && c < od) ? Wl[(size_t)c * in + r] : 0.f; };
+    o_wf[l] = pack_stage(blob, 0, (od + 31) / 32, (in + 7) / 8, Af);
+    o_wb[l] = pack_stage(blob, 0, (in + 31) / 32, (od + 7) / 8, Ab);
+    h_wf[l] = pack_stage_h(hblob, 0, (od + 31) / 32, (in + 15) / 16, ((in + 15) / 16) * 128, Af, &usf[l]);
+    h_wb[l] = pack_stage_h(hblob, 0, (in + 31) / 32, (od + 15) / 16, ((od + 15) / 16) * 128, Ab, &usb[l]);
     o_b[l] = blob.alloc(HM_ANY_MAX_WIDTH);
     for (int f = 0; f < od; ++f) blob.host[o_b[l] + f] = bias[l][f];
     o_g[l] = o_be[l] = 0;
@@ -258,10 +263,13 @@ extern "C" int hm_decoder_create_arch(const hm_decoder_arch* arch, const float* 
   d->L = L;
   d->precision = 0;
   d->generic = 1;
-  d->blob_bytes = blob.host.size() * sizeof(float);
+  const size_t fbytes = (blob.host.size() * sizeof(float) + 255) & ~size_t(255);
+  d->blob_bytes = fbytes + hblob.size() * sizeof(uint16_t);
   hipError_t e = hipMalloc(&d->d_blob, d->blob_bytes);
   if (e != hipSuccess) { hm_set_error("hipMalloc(%zu) failed: %s", d->blob_bytes, hipGetErrorString(e)); delete d; return -2; }
-  e = hipMemcpy(d->d_blob, blob.host.data(), d->blob_bytes, hipMemcpyHostToDevice);
+  e = hipMemcpy(d->d_blob, blob.host.data(), blob.host.size() * sizeof(float), hipMemcpyHostToDevice);
+  if (e == hipSuccess)
+    e = hipMemcpy(static_cast<char*>(d->d_blob) + fbytes, hblob.data(), hblob.size() * sizeof(uint16_t), hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMalloc(&d->d_any_slab, any_slab_bytes(n_ln));
   if (e != hipSuccess) {
     hm_set_error("device allocation / copy failed: %s", hipGetErrorString(e));
@@ -275,6 +283,10 @@ extern "C" int hm_decoder_create_arch(const hm_decoder_arch* arch, const float* 
     ly.wf = base + o_wf[l]; ly.wb = base + o_wb[l]; ly.bias = base + o_b[l];
     ly.gamma = arch->layer_norm[l] ? base + o_g[l] : nullptr;
     ly.beta = arch->layer_norm[l] ? base + o_be[l] : nullptr;
+    const char* hbase = static_cast<const char*>(d->d_blob) + fbytes;
+    ly.wfh = hbase + h_wf[l] * sizeof(uint16_t); ly.wbh = hbase + h_wb[l] * sizeof(uint16_t);
+    ly.kf16 = (arch->in_dim[l] + 15) / 16; ly.kb16 = (arch->out_dim[l] + 15) / 16;
+    ly.usf = usf[l]; ly.usb = usb[l];
     ly.in_dim = arch->in_dim[l]; ly.out_dim = arch->out_dim[l]; ly.cat = arch->cat[l];
     ly.ln = arch->layer_norm[l] ? 1 : 0;
   }
@@ -294,8 +306,8 @@ extern "C" int hm_decoder_latent_dim(const hm_decoder_s* d) { return d ? d->L : 
 
 extern "C" int hm_decoder_set_precision(hm_decoder_s* d, int precision) {
   if (d == nullptr) { hm_set_error("null decoder"); return -1; }
-  if (d->generic && precision != 0) {
-    hm_set_error("a decoder built by hm_decoder_create_arch runs in exact fp32 (precision 0) only"); return -1; }
+  if (d->generic && precision != 0 && precision != 1) {
+    hm_set_error("a decoder built by hm_decoder_create_arch runs in exact fp32 (precision 0) or f16x3 (precision 1) only"); return -1; }
   if (precision < 0 || precision > 3) { hm_set_error("precision must be 0 (f32), 1 (f16x3), 2 (f16x3f_f16b) or 3 (f16)"); return -1; }
   d->precision = precision;
   return 0;

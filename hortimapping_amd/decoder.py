@@ -152,7 +152,7 @@ class DecoderWeights:
                        "hm_decoder_create_arch")
         self.handle = h
         default = os.environ.get("HM_PRECISION", "")
-        if default and not self.generic:        # an any-architecture handle computes in exact fp32 only
+        if default and (not self.generic or default in ("f32", "f16x3")):   # any-architecture handles: f32 and f16x3 only
             self.set_precision(default)
 
     PRECISIONS = {"f32": 0, "f16x3": 1, "f16x3f_f16b": 2, "f16": 3}
@@ -161,7 +161,7 @@ class DecoderWeights:
         """'f32' (exact fp32 MFMA, default), 'f16x3' (fp16 MFMA, hi/lo split operands, ~2^-22 relative) or the
         mixed 'f16x3f_f16b' (forward as f16x3, backward in one fp16 pass: Jacobians ~1e-3 relative, NOT fp32-class) or
         'f16' (plain fp16 MFMA decoder of BASELINE.json configs[4]: everything ~1e-3 relative).  A decoder of a
-        non-shipped layer table (`self.generic`) has the exact-fp32 kernel only: any other name is refused by the library."""
+        non-shipped layer table (`self.generic`) has 'f32' and 'f16x3' kernels: the other two names are refused by the library."""
         _lib.check(_lib.lib().hm_decoder_set_precision(self.handle, self.PRECISIONS[name]), "hm_decoder_set_precision")
         return self
 

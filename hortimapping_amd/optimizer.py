@@ -436,7 +436,7 @@ class Optimizer(object):
             self.decoder = decoder
         else:                                   # the reference passes an nn.Module (optimizer.py:17)
             self.decoder = DecoderWeights.from_module(decoder)
-            if not os.environ.get("HM_PRECISION") and not self.decoder.generic:
+            if not os.environ.get("HM_PRECISION"):
                 # fp32-class results at 3 x the speed; instances whose activations leave the fp16 range are rerun in
                 # exact fp32 automatically (optimize_batch, retry_f32), so the behaviour is the reference's either way
                 self.decoder.set_precision("f16x3")

@@ -44,7 +44,7 @@ def main(config, dump_jobs):
     voxels_dim = int(2 * object_radius_max_m * 1e3 / float(cfg["vis"]["mc_res_mm"]))
     deepsdf_baseline = cfg["baseline_name"] == "DeepSDF"
     mesh_extractor = MeshExtractor(decoder, code_len=code_len, voxels_dim=voxels_dim, cube_radius=object_radius_max_m)
-    if not os.environ.get("HM_PRECISION") and not decoder.generic:   # (a non-shipped layer table has the exact-f32 kernel only)
+    if not os.environ.get("HM_PRECISION"):
         # fp32-class arithmetic at three times the speed of exact fp32; an instance whose activations leave the fp16 range
         # is rerun in exact fp32 by the Optimizer itself (hortimapping_amd/optimizer.py: retry_f32)
         decoder.set_precision("f16x3")

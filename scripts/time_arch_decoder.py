@@ -45,7 +45,9 @@ def main():
     p = S.make_synthetic_decoder(256, seed=2)
     rows = []
     for label, dec in (("shipped table, specialised f32 kernel", DecoderWeights.from_params(p)),
-                       ("shipped table, any-architecture kernel", DecoderWeights.from_params(p, force_generic=True))):
+                       ("shipped table, any-architecture kernel f32", DecoderWeights.from_params(p, force_generic=True)),
+                       ("shipped table, specialised f16x3 kernel", DecoderWeights.from_params(p).set_precision("f16x3")),
+                       ("shipped table, any-architecture f16x3", DecoderWeights.from_params(p, force_generic=True).set_precision("f16x3"))):
         for mode in (0, 1):
             t, wall, lo, hi = timeit(dec, B, n, mode)
             rows.append((label, mode, t, flops_per_query(dec.table, mode) * B * n / t / 1e12, wall, lo, hi))
@@ -53,13 +55,15 @@ def main():
                       ("8 x 512, latent_in [4], LayerNorm", dict(latent_dim=256, dims=[512] * 8, latent_in=[4], norm_layers=list(range(8)), weight_norm=False)),
                       ("6 x 128 plain", dict(latent_dim=32, dims=[128] * 6))):
         dec = DecoderWeights.from_params(S.make_arch_decoder(seed=1, **kw))
-        for mode in (0, 1):
-            t, wall, lo, hi = timeit(dec, B, n, mode)
-            rows.append((label, mode, t, flops_per_query(dec.table, mode) * B * n / t / 1e12, wall, lo, hi))
+        for arith in ("f32", "f16x3"):
+            dec.set_precision(arith)
+            for mode in (0, 1):
+                t, wall, lo, hi = timeit(dec, B, n, mode)
+                rows.append((label + ", " + arith, mode, t, flops_per_query(dec.table, mode) * B * n / t / 1e12, wall, lo, hi))
     print("decode API, %d instances x %d queries (pose_dim 7); TFLOP/s on the dense layer-table flop" % (B, n))
     print("(median of 20 calls by device events, memset of the output buffers included; [min .. max]; host wall per call)")
     for label, mode, t, tf, wall, lo, hi in rows:
-        print("%-42s %-8s %8.3f ms  %7.1f TFLOP/s   [%.3f .. %.3f]  wall %.3f" %
+        print("%-48s %-8s %8.3f ms  %7.1f TFLOP/s   [%.3f .. %.3f]  wall %.3f" %
               (label, "fwd" if mode == 0 else "fwd+bwd", t * 1e3, tf, lo * 1e3, hi * 1e3, wall * 1e3))
 
 

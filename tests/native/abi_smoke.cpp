@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 #include <cmath>
 #include <cstdio>
+#include <string.h>
 #include <vector>
 #include "hortimapping_amd.h"
 
@@ -74,6 +75,50 @@ int main() {
   // a refused request must come back as an error code with a message, not a crash
   if (hm_decode_batch(dec, B, d_lat, L, d_pts, d_nq, 63, d_cb, d_y, d_J, ldJ, 7, 1, st) == 0) { printf("stride 63 accepted\n"); return 6; }
   if (hm_last_error() == nullptr || hm_last_error()[0] == 0) { printf("no error text\n"); return 7; }
+  // ---- hm_decoder_create_arch: the same closed-form function as a 64 - 64 - 1 table (three Linear layers, no skip) ----
+  {
+    const int Hs = 64;
+    std::vector<float> A0((size_t)Hs * D0, 0.f), A1((size_t)Hs * Hs, 0.f), A2(Hs, 0.f), z64(Hs, 0.f);
+    for (int c = 0; c < 3; ++c) A0[(size_t)c * D0 + L + c] = 1.f;
+    A0[(size_t)3 * D0 + 0] = 1.f;
+    for (int i = 0; i < Hs; ++i) A1[(size_t)i * Hs + i] = 1.f;
+    A2[0] = 0.5f; A2[1] = 0.25f; A2[2] = -1.f; A2[3] = 2.f;
+    hm_decoder_arch arch;
+    memset(&arch, 0, sizeof(arch));
+    arch.latent_dim = L; arch.n_lin = 3;
+    arch.in_dim[0] = D0; arch.out_dim[0] = Hs; arch.in_dim[1] = Hs; arch.out_dim[1] = Hs; arch.in_dim[2] = Hs; arch.out_dim[2] = 1;
+    const float* Wa[HM_MAX_LIN] = {A0.data(), A1.data(), A2.data()};
+    const float* ba[HM_MAX_LIN] = {z64.data(), z64.data(), b8.data()};
+    hm_decoder_t dany = nullptr;
+    HM(hm_decoder_create_arch(&arch, Wa, ba, nullptr, nullptr, &dany));
+    if (hm_decoder_set_precision(dany, 3) == 0) { printf("plain fp16 accepted by an any-architecture decoder\n"); return 6; }
+    for (int prec = 0; prec < 2; ++prec) {
+    HM(hm_decoder_set_precision(dany, prec));
+    CK(hipMemsetAsync(d_J, 0, (size_t)B * NS * ldJ * 4, st));
+    HM(hm_decode_batch(dany, B, d_lat, L, d_pts, d_nq, NS, d_cb, d_y, d_J, ldJ, 7, 1, st));
+    CK(hipStreamSynchronize(st));
+    std::vector<float> y(B * NS), J((size_t)B * NS * ldJ);
+    CK(hipMemcpy(y.data(), d_y, y.size() * 4, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(J.data(), d_J, J.size() * 4, hipMemcpyDeviceToHost));
+    for (int b = 0; b < B; ++b)
+      for (int i = 0; i < nq_h[b]; ++i) {
+        const float* p = &pts[((size_t)b * NS + i) * 4];
+        auto rl = [](float v) { return v > 0.f ? v : 0.f; };
+        const float z0 = lat[(size_t)b * L];
+        const float want = std::tanh(0.5f * rl(p[0]) + 0.25f * rl(p[1]) - rl(p[2]) + 2.f * rl(z0) + 0.1f), dy = 1.f - want * want;
+        const float* row = &J[((size_t)b * NS + i) * ldJ];
+        if (std::fabs(y[b * NS + i] - want) > 2e-6f || std::fabs(row[L + 7] - want) > 2e-6f ||
+            std::fabs(row[L] - dy * 0.5f * (p[0] > 0)) > 2e-6f || std::fabs(row[0] - dy * 2.f * (z0 > 0)) > 2e-6f) {
+          printf("any-architecture mismatch prec %d b %d i %d: y %.8f want %.8f\n", prec, b, i, y[b * NS + i], want);
+          return 5;
+        }
+      }
+    }
+    arch.out_dim[1] = 63;                        // a table that does not chain must be refused with a message
+    hm_decoder_t bad = nullptr;
+    if (hm_decoder_create_arch(&arch, Wa, ba, nullptr, nullptr, &bad) == 0) { printf("bad table accepted\n"); return 6; }
+    HM(hm_decoder_destroy(dany));
+  }
   // ---- hm_optimize_batch (mode 1 = Optimizer.shape_opt_deepsdf, optimizer.py:306-429) with a closed-form answer ----
   // Points on the +x axis (y = z = 0), T_ow = identity, latent z0 > 0: sdf_i = tanh(0.5 x_i + 2 z0 + 0.1), only z0 has a
   // non-zero Jacobian column J_i = 2 (1 - sdf_i^2).  One LM iteration (optimizer.py:362-397):

@@ -24,14 +24,19 @@ def _no_process_default(monkeypatch):
     monkeypatch.delenv("HM_PRECISION", raising=False)
 
 
+ARITH = ["f32", "f16x3"]          # the two fp32-class arithmetics an any-architecture handle offers; SAME tolerances
+
+
+@pytest.mark.parametrize("arith", ARITH)
 @pytest.mark.parametrize("name", sorted(ARCH_SPECS))
-def test_g17_decode_and_jacobian_vs_the_reference_class(name):
+def test_g17_decode_and_jacobian_vs_the_reference_class(name, arith):
     """decode_sdf / get_batch_sdf_jacobian (utils.py:144-193) on layer tables the fixed-architecture kernels refuse."""
     from hortimapping_amd import utils as U
     from hortimapping_amd.decoder import DecoderWeights
     g = load(f"g17_arch_{name}")
     dec = DecoderWeights.from_params(arch_params(name))
     assert dec.generic and dec.precision == "f32"
+    dec.set_precision(arith)
     z, x = torch.from_numpy(g["z"]), torch.from_numpy(g["x"])
     assert relmax(U.decode_sdf(dec, z, x).cpu(), g["sdf"]) < 5e-6
     y, jac = U.get_batch_sdf_jacobian(dec, z, x)
@@ -40,15 +45,16 @@ def test_g17_decode_and_jacobian_vs_the_reference_class(name):
     assert relmax(jac.cpu()[:, 0], g["g"]) < 2e-5
 
 
+@pytest.mark.parametrize("arith", ARITH)
 @pytest.mark.parametrize("name", ["skip_wn", "layernorm", "tanh_wide", "deep_ln64"])
-def test_arch_decoder_vs_fp64_oracle_ragged(name):
+def test_arch_decoder_vs_fp64_oracle_ragged(name, arith):
     """Ragged per-instance counts (tails, an empty instance, more tiles than one pass), all three pose layouts."""
     from hortimapping_amd import ops
     from hortimapping_amd.decoder import DecoderWeights
     from oracle import hm_oracle as O
     p = arch_params(name)
     L = int(p["latent_dim"])
-    dec = DecoderWeights.from_params(p)
+    dec = DecoderWeights.from_params(p).set_precision(arith)
     od = O.fold_decoder(p).to(torch.float64)
     gen = torch.Generator().manual_seed(L + len(name))
     nq = [1, 63, 64, 65, 200, 0]
@@ -79,11 +85,12 @@ def test_arch_decoder_vs_fp64_oracle_ragged(name):
             assert float(J[b, k:].abs().max()) == 0.0                    # rows beyond n_q untouched
 
 
-def test_arch_decoder_many_tiles_equal_single_tiles():
+@pytest.mark.parametrize("arith", ARITH)
+def test_arch_decoder_many_tiles_equal_single_tiles(arith):
     """More tiles than persistent workgroups (grid-stride loop, LayerNorm slab reuse): bits equal a small launch's."""
     from hortimapping_amd import ops
     from hortimapping_amd.decoder import DecoderWeights
-    dec = DecoderWeights.from_params(arch_params("layernorm"))
+    dec = DecoderWeights.from_params(arch_params("layernorm")).set_precision(arith)
     gen = torch.Generator().manual_seed(3)
     B, n = 40, 1024                                                     # 640 tiles > 512 workgroups
     lat = (0.3 * torch.randn(B, 32, generator=gen)).cuda()
@@ -98,14 +105,36 @@ def test_arch_decoder_many_tiles_equal_single_tiles():
         assert torch.equal(y[b, 448:512], y1[0]) and torch.equal(J[b, 448:512], J1[0])
 
 
-def test_arch_decoder_is_f32_only_and_entry_points_keep_it_there():
+def test_arch_decoder_offers_the_two_fp32_class_arithmetics_only():
     from hortimapping_amd.decoder import DecoderWeights
     dec = DecoderWeights.from_params(arch_params("plain"))
-    for name in ("f16x3", "f16x3f_f16b", "f16"):
+    for name in ("f16x3f_f16b", "f16"):
         with pytest.raises(RuntimeError, match="exact fp32"):
             dec.set_precision(name)
     assert dec.precision == "f32" and dec.f32_twin() is dec
-    dec.set_precision("f32")
+    dec.set_precision("f16x3")
+    tw = dec.f32_twin()
+    assert dec.precision == "f16x3" and tw is not dec and tw.generic and tw.precision == "f32"
+
+
+def test_arch_decoder_f16x3_range_guard_poisons_the_tile():
+    """Activations beyond 65504 cannot be held as fp16 hi / lo pairs: the tile returns NaN sdf / Jacobian rows (never
+    silent garbage), the exact-f32 kernel carries on -- the policy of the fixed-architecture f16x3 kernel."""
+    from hortimapping_amd import ops
+    from hortimapping_amd.decoder import DecoderWeights
+    p = arch_params("plain")
+    p["lin0.weight"] = (p["lin0.weight"] * 1e6).astype(np.float32)
+    dec = DecoderWeights.from_params(p)
+    lat = (0.3 * torch.randn(2, 32, generator=torch.Generator().manual_seed(1))).cuda()
+    pts4 = torch.zeros(2, 64, 4).cuda()
+    pts4[..., :3] = 0.3
+    nq = torch.tensor([64, 10], dtype=torch.int32).cuda()
+    y32, J32 = ops.decode_batch(dec, lat, pts4, nq, mode=1, pose_dim=7)
+    assert torch.isfinite(y32[0]).all() and torch.isfinite(J32[0]).all()
+    dec.set_precision("f16x3")
+    y, J = ops.decode_batch(dec, lat, pts4, nq, mode=1, pose_dim=7)
+    assert torch.isnan(y[0]).all() and torch.isnan(y[1, :10]).all() and torch.isnan(J[0, :, :40]).all()
+    assert float(y[1, 10:].abs().max()) == 0.0 and float(J[1, 10:].abs().max()) == 0.0      # rows beyond n_q untouched
 
 
 class _MiniDecoder(torch.nn.Module):
@@ -141,15 +170,16 @@ def _instances(p, ids, **kw):
     return [S.make_instance(None, None, int(p["latent_dim"]), i, sdf_fn_factory=factory, **kw) for i in ids]
 
 
+@pytest.mark.parametrize("arith", ARITH)
 @pytest.mark.parametrize("pose_known", [True, False])
-def test_joint_lm_loop_on_another_layer_table_vs_oracle(pose_known):
+def test_joint_lm_loop_on_another_layer_table_vs_oracle(pose_known, arith):
     """shape_pose_joint_opt (optimizer.py:28-302) with a 4 x 128 / latent_in = [2] decoder: iteration counts equal, state
     at the tolerance of the fixed-architecture f32 trajectory tests."""
     from hortimapping_amd import optimizer as HO, workloads as W
     from hortimapping_amd.decoder import DecoderWeights
     from oracle import hm_oracle as O
     p = _analytic_arch()
-    dec = DecoderWeights.from_module(_MiniDecoder(p, True, False))
+    dec = DecoderWeights.from_module(_MiniDecoder(p, True, False)).set_precision(arith)
     assert dec.generic
     od = O.fold_decoder(p)
     cfg = W.c2_opt_cfg(max_iter=4, n_sample_on_ray=16, n_frame=1)
@@ -172,7 +202,8 @@ def test_shape_only_loop_with_layernorm_decoder_vs_oracle():
     od = O.fold_decoder(p)
     cfg = {"device": "cuda", "opt": W.c2_opt_cfg(max_iter=3)}
     opt = HO.Optimizer(cfg, _MiniDecoder(p, False, False), None, None)
-    assert opt.decoder.generic and opt.decoder.precision == "f32" and sorted(opt.decoder.ln) == [0, 1, 2]
+    # the drop-in class picks f16x3 (with its exact-f32 retry) for any-architecture decoders as well
+    assert opt.decoder.generic and opt.decoder.precision == "f16x3" and sorted(opt.decoder.ln) == [0, 1, 2]
     gen = torch.Generator().manual_seed(9)
     pts = 0.05 * torch.randn(300, 3, generator=gen) + torch.tensor([0.0, 0.0, 0.5])
     T_ow = torch.eye(4)
