@@ -62,8 +62,10 @@ int hm_decoder_latent_dim(hm_decoder_t dec);
  * HOST pointers to the folded (weight-norm applied) row-major (out_dim[l], in_dim[l]) fp32 matrices; ln_weight[l] /
  * ln_bias[l] (out_dim[l] floats) are read for layers with layer_norm[l] only (the arrays may be NULL without any).
  * Limits: n_lin <= HM_MAX_LIN, every width <= 512, latent_dim as for hm_decoder_create.  Such a handle computes in
- * exact fp32 on the matrix cores (hm_decoder_set_precision accepts 0 only) and is accepted by every entry point that
- * takes an hm_decoder_t; the shipped 8 x 512 / latent_in = [4] models are faster through hm_decoder_create. */
+ * exact fp32 (default) or f16x3 on the matrix cores (hm_decoder_set_precision accepts 0 and 1; f16x3 with the range
+ * policy stated there) and is accepted by every entry point that takes an hm_decoder_t; hm_optimize_batch runs it
+ * with the render chain as separate launches.  The shipped 8 x 512 / latent_in = [4] models are faster through
+ * hm_decoder_create. */
 #define HM_MAX_LIN 16
 typedef struct hm_decoder_arch {
   int latent_dim;
