@@ -77,7 +77,7 @@ __device__ __forceinline__ void run_gemm(f32x16 (&acc)[2][2], const float* wp, i
   else if (u0) gemm_loop<true, false>(acc, wp0, wp1, n_kg, xs4, lane);
 }
 
-template <int MODE>
+template <int MODE, bool LN>
 __global__ __launch_bounds__(512, 2) void k_decoder_any(const AnyArgs a) {
   __shared__ f32x4 xs4[(ANY_W / 4) * TQ];   // 128 KiB
   __shared__ float red[2 * NWAVE * 64];
@@ -143,7 +143,7 @@ __global__ __launch_bounds__(512, 2) void k_decoder_any(const AnyArgs a) {
       }
       // bias (+ LayerNorm :96-101) + ReLU :102
       float mean[2] = {0.f, 0.f}, rstd[2] = {1.f, 1.f};
-      if (ly.ln) {
+      if (LN && ly.ln) {
         float s[2] = {0.f, 0.f};
 #pragma unroll
         for (int sl = 0; sl < 2; ++sl) {
@@ -187,7 +187,7 @@ __global__ __launch_bounds__(512, 2) void k_decoder_any(const AnyArgs a) {
         rstd[0] = 1.f / sqrtf(rstd[0] / (float)ly.out_dim + 1e-5f);   // nn.LayerNorm default eps, biased variance
         rstd[1] = 1.f / sqrtf(rstd[1] / (float)ly.out_dim + 1e-5f);
       }
-      float* xh = (MODE == 1 && ly.ln) ? slab + (size_t)ln_i * SLAB : nullptr;
+      float* xh = (LN && MODE == 1 && ly.ln) ? slab + (size_t)ln_i * SLAB : nullptr;
       if (xh != nullptr && w == 0 && hi == 0) { xh[ANY_W * 64 + qa] = rstd[0]; xh[ANY_W * 64 + 32 + qa] = rstd[1]; }
       unsigned long long bits = 0;
 #pragma unroll
@@ -204,7 +204,7 @@ __global__ __launch_bounds__(512, 2) void k_decoder_any(const AnyArgs a) {
             for (int j = 0; j < 4; ++j) {
               const int r = f4 + j;
               float val;
-              if (ly.ln) {
+              if (LN && ly.ln) {
                 const float h = (acc[sl][nb][4 * g + j] - mean[nb]) * rstd[nb];
                 if (xh != nullptr) xh[r * 64 + nb * 32 + qa] = h;
                 val = fmaf(h, ly.gamma[r], ly.beta[r]);
@@ -220,7 +220,7 @@ __global__ __launch_bounds__(512, 2) void k_decoder_any(const AnyArgs a) {
         }
       }
       mk[l] = bits;
-      if (ly.ln) ++ln_i;
+      if (LN && ly.ln) ++ln_i;
       const int cat = a.dec.lay[l + 1].cat;
       if (cat != 0) {    // :87-90 x = cat[x, input] (latent_in) or cat[x, xyz] (xyz_in_all)
         __syncthreads();
@@ -289,7 +289,7 @@ __global__ __launch_bounds__(512, 2) void k_decoder_any(const AnyArgs a) {
 #pragma unroll
           for (int i = 0; i < 16; ++i)
             acc[sl][nb][i] = ((bits >> (sl * 32 + nb * 16 + i)) & 1ull) ? acc[sl][nb][i] : 0.f;
-      if (lp.ln) {
+      if (LN && lp.ln) {
         --ln_i;
         const float* xh = slab + (size_t)ln_i * SLAB;
         const float rs[2] = {xh[ANY_W * 64 + qa], xh[ANY_W * 64 + 32 + qa]};
@@ -393,7 +393,7 @@ __device__ __forceinline__ void run_gemm_h(f32x16 (&acc)[2][2], const void* wp, 
   else if (u0) gemm_loop_h<true, false>(acc, wp0, wp1, n_k16, xh, xl, lane);
 }
 
-template <int MODE>
+template <int MODE, bool LN>
 __global__ __launch_bounds__(512, 2) void k_decoder_any_h(const AnyArgs a) {
   __shared__ f16x8 xh[64 * TQ];             // 64 KiB: hi plane  X[k/8][q][8]
   __shared__ f16x8 xl[64 * TQ];             // 64 KiB: lo plane (scaled by 2^11)
@@ -471,7 +471,7 @@ __global__ __launch_bounds__(512, 2) void k_decoder_any_h(const AnyArgs a) {
       }
       // bias (+ LayerNorm :96-101) + ReLU :102
       float mean[2] = {0.f, 0.f}, rstd[2] = {1.f, 1.f};
-      if (ly.ln) {
+      if (LN && ly.ln) {
         float s[2] = {0.f, 0.f};
 #pragma unroll
         for (int sl = 0; sl < 2; ++sl) {
@@ -515,7 +515,7 @@ __global__ __launch_bounds__(512, 2) void k_decoder_any_h(const AnyArgs a) {
         rstd[0] = 1.f / sqrtf(rstd[0] / (float)ly.out_dim + 1e-5f);   // nn.LayerNorm default eps, biased variance
         rstd[1] = 1.f / sqrtf(rstd[1] / (float)ly.out_dim + 1e-5f);
       }
-      float* xh = (MODE == 1 && ly.ln) ? slab + (size_t)ln_i * SLAB : nullptr;
+      float* xh = (LN && MODE == 1 && ly.ln) ? slab + (size_t)ln_i * SLAB : nullptr;
       if (xh != nullptr && w == 0 && hi == 0) { xh[ANY_W * 64 + qa] = rstd[0]; xh[ANY_W * 64 + 32 + qa] = rstd[1]; }
       unsigned long long bits = 0;
 #pragma unroll
@@ -532,7 +532,7 @@ __global__ __launch_bounds__(512, 2) void k_decoder_any_h(const AnyArgs a) {
             for (int j = 0; j < 4; ++j) {
               const int r = f4 + j;
               float val;
-              if (ly.ln) {
+              if (LN && ly.ln) {
                 const float h = (acc[sl][nb][4 * g + j] - mean[nb]) * rstd[nb];
                 if (xh != nullptr) xh[r * 64 + nb * 32 + qa] = h;
                 val = fmaf(h, ly.gamma[r], ly.beta[r]);
@@ -548,7 +548,7 @@ __global__ __launch_bounds__(512, 2) void k_decoder_any_h(const AnyArgs a) {
         }
       }
       mk[l] = bits;
-      if (ly.ln) ++ln_i;
+      if (LN && ly.ln) ++ln_i;
       const int cat = a.dec.lay[l + 1].cat;
       if (cat != 0) {    // :87-90 x = cat[x, input] (latent_in) or cat[x, xyz] (xyz_in_all)
         __syncthreads();
@@ -626,7 +626,7 @@ __global__ __launch_bounds__(512, 2) void k_decoder_any_h(const AnyArgs a) {
 #pragma unroll
           for (int i = 0; i < 16; ++i)
             acc[sl][nb][i] = ((bits >> (sl * 32 + nb * 16 + i)) & 1ull) ? acc[sl][nb][i] : 0.f;
-      if (lp.ln) {
+      if (LN && lp.ln) {
         --ln_i;
         const float* xh = slab + (size_t)ln_i * SLAB;
         const float rs[2] = {xh[ANY_W * 64 + qa], xh[ANY_W * 64 + 32 + qa]};
@@ -743,14 +743,21 @@ int launch_decoder_any(const hm_decoder_s* dec, int B, const float* d_pts, const
   a.n_tiles = B * (n_stride / TQ);
   if (a.n_tiles == 0) return 0;
   const int grid = a.n_tiles < ANY_GRID ? a.n_tiles : ANY_GRID;
+  const bool ln = dec->any.n_ln > 0;      // tables without LayerNorm run kernels compiled without its code paths
+#define HM_ANY_LAUNCH(K, M)                                                                     \
+  do {                                                                                          \
+    if (ln) hipLaunchKernelGGL((K<M, true>), dim3(grid), dim3(512), 0, stream, a);              \
+    else hipLaunchKernelGGL((K<M, false>), dim3(grid), dim3(512), 0, stream, a);                \
+  } while (0)
   if (dec->precision == 1) {
-    if (mode == 0) hipLaunchKernelGGL((k_decoder_any_h<0>), dim3(grid), dim3(512), 0, stream, a);
-    else hipLaunchKernelGGL((k_decoder_any_h<1>), dim3(grid), dim3(512), 0, stream, a);
+    if (mode == 0) HM_ANY_LAUNCH(k_decoder_any_h, 0); else HM_ANY_LAUNCH(k_decoder_any_h, 1);
   } else if (dec->precision != 0) {
     hm_set_error("any-architecture decoder: precision %d not available (0 = exact fp32, 1 = f16x3)", dec->precision);
     return -1;
-  } else if (mode == 0) hipLaunchKernelGGL((k_decoder_any<0>), dim3(grid), dim3(512), 0, stream, a);
-  else hipLaunchKernelGGL((k_decoder_any<1>), dim3(grid), dim3(512), 0, stream, a);
+  } else {
+    if (mode == 0) HM_ANY_LAUNCH(k_decoder_any, 0); else HM_ANY_LAUNCH(k_decoder_any, 1);
+  }
+#undef HM_ANY_LAUNCH
   HM_CHECK_HIP(hipGetLastError());
   return 0;
 }
