@@ -112,3 +112,22 @@ def test_lm_loops_on_other_layer_tables_oracle_equals_live_reference():
     zo, _, no = O.shape_opt_deepsdf(od, cfgd["opt"], torch.zeros(32), T_ow.clone(), pts)
     assert nr == no == 3
     assert float((zo - zr).abs().max() / zr.abs().max()) < 1e-3
+
+
+def test_fuzz_slice_layer_tables_oracle_equals_live_reference_class():
+    """A 30-table slice of `scripts/fuzz_arch_oracle_vs_reference.py` (the 300-table record is
+    profiles/r05_oracle_fuzz_arch.txt): random `dims` / `latent_in` / `xyz_in_all` / weight norm or LayerNorm / `use_tanh`
+    tables built by the reference's own `Decoder` class; its `decode_sdf` and input gradients against the oracle's generalised
+    restatement (2e-6 / 2e-5; queries sitting on a ReLU kink are identified with the fp64 oracle and not compared)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
+    import fuzz_arch_oracle_vs_reference as FA
+    from oracle import ref_shim
+    ns = ref_shim.import_reference()
+    bad = []
+    for seed in range(7000, 7030):
+        ok, kw, errs = FA.check_case(ns, seed)
+        if not ok:
+            bad.append((seed, kw, errs))
+    assert not bad, bad
