@@ -107,7 +107,7 @@ LN_EPS = 1e-5     # nn.LayerNorm default (deep_sdf_decoder.py:62)
 
 def _layers(dec: FoldedDecoder, u, keep: bool):
     """Decoder.forward (deep_sdf_decoder.py:75-110) in eval mode (dropout inert).  Returns the pre-tanh output (n,), the
-    inner tanh value when `use_tanh` (else None) and, with keep=True, per hidden layer (ReLU mask, x_hat, rstd)."""
+    inner tanh value when `use_tanh` (else None) and, with keep=True, per hidden layer (ReLU mask, x_hat, rstd, kink margin)."""
     n = len(dec.Ws)
     cat = dec.cat_table()
     h = u
@@ -129,7 +129,8 @@ def _layers(dec: FoldedDecoder, u, keep: bool):
             mk = a > 0
             h = a * mk                                      # :102 relu
             if keep:
-                saved.append((mk, xh, rstd))
+                # 4th entry (tests only): how close this layer's closest unit sits to its ReLU kink, relative to the layer's scale
+                saved.append((mk, xh, rstd, a.abs().min(dim=1).values / a.abs().max(dim=1).values.clamp_min(1e-300)))
         else:
             h = a
     pre = h[:, 0]
@@ -172,7 +173,7 @@ def decoder_jacobian(dec: FoldedDecoder, z, x):
         elif cat[l] == 2:
             g_u[:, -3:] = g_u[:, -3:] + G[:, -3:]
             G = G[:, :-3]
-        mk, xh, rstd = saved[l - 1]
+        mk, xh, rstd = saved[l - 1][:3]
         G = G * mk
         if xh is not None:                                  # LayerNorm backward
             gg = G * dec.ln[l - 1][0]

@@ -278,3 +278,59 @@ def test_g18_joint_loop_vs_records_of_the_reference_loop(name, arith):
     # tolerances of tests/test_arch_cpu.py::test_g18_oracle_loop_... (free pose: the CPU oracle itself is 2e-4 from the reference)
     tz, tT = (1e-3, 1e-4) if bool(g["pose_known"]) else (2e-3, 1e-3)
     assert relmax(r.latent, g["latent"]) < tz and relmax(r.T_ow, g["T_ow"]) < tT
+
+
+def _draw_gpu_table(seed):
+    """A random layer table inside the limits of hm_decoder_create_arch (latent 32 / 64, widths <= 512, <= 16 layers)."""
+    rs = np.random.RandomState(seed)
+    L = int(rs.choice([32, 64]))
+    n_hidden = int(rs.randint(1, 9))
+    latent_in = sorted(int(i) for i in rs.choice(np.arange(1, n_hidden + 1), size=int(rs.randint(0, min(3, n_hidden) + 1)), replace=False))
+    pick = lambda: int(rs.choice([rs.randint(L + 12, 513), rs.choice([L + 12, 128, 255, 256, 257, 509, 511, 512])]))   # noqa: E731
+    return dict(latent_dim=L, dims=[pick() for _ in range(n_hidden)], latent_in=latent_in,
+                norm_layers=sorted(int(i) for i in np.flatnonzero(rs.rand(n_hidden + 1) < 0.6)), weight_norm=bool(rs.rand() < 0.5),
+                xyz_in_all=bool(rs.rand() < 0.35), use_tanh=bool(rs.rand() < 0.3))
+
+
+@pytest.mark.parametrize("arith", ARITH)
+def test_fuzz_random_layer_tables_vs_fp64_oracle(arith):
+    """40 random layer tables (odd widths, several latent_in layers, xyz_in_all, LayerNorm / weight norm, use_tanh, 2 ... 9
+    Linear layers): sdf and Jacobian rows of two ragged instances against the fp64 oracle.  Queries with a hidden unit within
+    1e-5 (relative to its layer) of its ReLU kink are left out of the gradient comparison: there the gradient jumps between any
+    two arithmetics."""
+    from hortimapping_amd import ops, synthetic as S
+    from hortimapping_amd.decoder import DecoderWeights
+    from oracle import hm_oracle as O
+    n_kink = n_cmp = 0
+    worst = [0.0, 0.0]
+    for seed in range(9000, 9040):
+        kw = _draw_gpu_table(seed)
+        p = S.make_arch_decoder(seed=seed, **kw)
+        L = kw["latent_dim"]
+        dec = DecoderWeights.from_params(p).set_precision(arith)
+        assert dec.generic
+        od = O.fold_decoder(p).to(torch.float64)
+        gen = torch.Generator().manual_seed(seed)
+        nq = [70, 33]
+        lat = 0.3 * torch.randn(2, L, generator=gen)
+        pts = 0.3 * torch.randn(2, 128, 3, generator=gen)
+        pts4 = torch.zeros(2, 128, 4)
+        pts4[..., :3] = pts
+        y, J = ops.decode_batch(dec, lat.cuda(), pts4.cuda(), torch.tensor(nq, dtype=torch.int32).cuda(), mode=1, pose_dim=0)
+        y, J = y.cpu(), J.cpu()
+        for b, k in enumerate(nq):
+            yo, go = O.decoder_jacobian(od, lat[b], pts[b, :k])
+            saved = O._layers(od, O._inputs(od, lat[b], pts[b, :k]), True)[2]
+            ok = torch.ones(k, dtype=torch.bool)
+            for sv in saved:
+                ok &= sv[3] > 1e-5
+            n_kink += int((~ok).sum()); n_cmp += int(ok.sum())
+            # natural scales as floors: the last layer sums O(1) activations, so the sdf carries ~1e-7 ABSOLUTE rounding whatever
+            # its own size (seed 9005: max |sdf| 0.035, the fp32 CPU oracle itself is 3.4e-7 = 9.8e-6 relative from the fp64 one)
+            ey = relmax(y[b, :k], yo, 0.25)
+            eg = relmax(J[b, :k, :L + 3][ok], go[ok], 0.1) if ok.any() else 0.0
+            worst = [max(worst[0], ey), max(worst[1], eg)]
+            assert ey < 5e-6 and eg < 2e-5, (seed, kw, b, ey, eg)
+            assert float(J[b, k:].abs().max()) == 0.0
+    print(f"{arith}: 40 tables, {n_cmp} queries compared, {n_kink} on a kink; worst sdf {worst[0]:.1e}, Jacobian {worst[1]:.1e}")
+    assert n_kink < 0.25 * (n_cmp + n_kink)
