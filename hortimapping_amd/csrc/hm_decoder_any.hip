@@ -377,6 +377,10 @@ __global__ __launch_bounds__(512, 2) void k_decoder_any(const AnyArgs a) {
 }
 
 // ---- f16x3 variant (hm_decoder_set_precision 1): the same kernel on the fp16 matrix cores with hi / lo split operands ----
+// (Deliberately a second copy of the kernel text rather than one kernel templated on the arithmetic: the unified form -- a
+// Planes<H> policy for layout / store / K loop, 270 lines shorter -- was built and measured on the same tests: identical
+// results, but hipcc's register allocation of the f16x3 instance got worse (13 -> 55 spilled registers in the backward
+// epilogues) and the shipped table ran 306-311 instead of 351-364 TFLOP/s.  Keep the two in step by hand.)
 // element (k, q) of the two fp16 activation planes X[k/8][q][8] (hi, and lo scaled by 2^11)
 __device__ __forceinline__ void put_h(_Float16* xhs, _Float16* xls, int k, int q, float v) {
   const int i = (((k >> 3) * TQ + q) << 3) + (k & 7);
