@@ -58,6 +58,12 @@ struct DecoderDev {
   const float* w4z;              // [512][L]
   const float* b0;               // [512]
   const float* b4;               // [512]
+  // plain-fp16 kernel (hm_decoder_p.hip): per-wave weight streams (hm_pack.hip pack_stream_p)
+  const void* ps;                // [8 waves][ps_steps][2 row blocks][64 lanes][8 halves]
+  int ps_steps;                  // K-steps of 16 per wave stream (every stage padded to groups of 4, + slack)
+  int pgrp[NSTAGE];              // groups of 4 K-steps per stage
+  float pus[NSTAGE];             // 2^-shift per stage: accumulators hold 2^shift * (W X)
+  int pswap[NSTAGE];             // 1: slot 0 of wave w is block w + 8, slot 1 block w (stages with no valid block below 8)
 };
 
 // ---- any-architecture decoder (hm_decoder_any.hip): the layer table of deepsdf/networks/deep_sdf_decoder.py:29-72 ----

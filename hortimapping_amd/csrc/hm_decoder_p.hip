@@ -1,38 +1,46 @@
-// K1p: the fused decoder forward + input-gradient backward in PLAIN fp16 MFMA arithmetic (precision 3, "f16").
+// K1p: the fused decoder forward + input-gradient backward in PLAIN fp16 MFMA arithmetic (precision 3, "f16"), and the
+// screening pass of the f16x3 render chain (hm_optimize.hip: screen_pass).
 //
 // This is the arithmetic BASELINE.json names for configs[4] ("fp16 MFMA decoder"): every GEMM of the network is ONE
 // v_mfma_f32_32x32x16_f16 pass on fp16-rounded weights (per-stage power-of-two scale, hm_pack.hip) and fp16-rounded
 // activations, fp32 accumulation.  Results are fp16-class (~1e-3 relative), NOT the reference's fp32 -- never the
 // default; the parity tables in profiles/ say what that costs at the metric level.
 //
-// What the single plane buys: the activations of 128 queries fit the LDS (one fp16 plane [k/8][q][8] = 128 KiB, the
-// f16x3 kernel needs 128 KiB for 64), so every weight byte fetched from L2 serves 128 queries instead of 64 and only
-// the hi plane (half the bytes) is fetched at all: a quarter of the weight stream per query.  At the matrix rate of
-// its single pass the stream would still have to run at 32 B/clk/CU, and the measured K phase of a 512 x 512 stage is
-// ~26 k clocks against 16.4 k of MFMA (DESIGN.md section 8 has the trace and the micro-benchmarks): 0.31-0.33 of the
-// fp16 peak.  Tiling: 512 threads, wave w owns the
-// 32-row blocks {w, w+8} x four 32-query blocks (8 accumulators of 32x32 = 128 registers, plus 32 for the ReLU masks of
-// the 8 layers); A operands stream L2 -> VGPR two K-steps ahead (ring of three), B operands are refilled in place
-// from LDS right after their last use (one set), 8 MFMAs per K-step.
-// Stage list, ReLU masks in registers, latent folding, lin4^T latent partial parked in the J rows, VALU side paths
-// and the fp16 range guard are those of hm_decoder_h.hip (reference: deepsdf/networks/deep_sdf_decoder.py:75-110,
-// wild_completion/utils.py:112-193, loss.py:229-241).
+// Tiling: 128 queries per workgroup (one fp16 activation plane = 128 KiB of LDS), 512 threads; wave w owns the 32-row
+// blocks {w, w + 8} x four 32-query blocks (8 accumulators of 32x32 = 128 registers).  Round 6 rewrite:
+//  * WEIGHT STREAMS.  Each wave reads one contiguous stream (hm_pack.hip: pack_stream_p) in the order it consumes it, so
+//    the ring of FOUR A-operand sets (fetched three K-steps ahead, L2 -> VGPR, never through LDS: no sharing inside the
+//    workgroup) runs ACROSS stage boundaries: the first three steps of the next stage are in flight while the epilogue
+//    runs, no stage starts with an exposed L2 round trip.
+//  * K PERMUTATION.  Inside a K-step lane half h holds k = 16 t + 4 h + {0..3} and 16 t + 8 + 4 h + {0..3}: exactly the
+//    rows one lane owns in the 32x32 accumulator layout, so the epilogue writes whole 16-byte activation units
+//    X[unit 2 t + h][query][8] with one conflict-free ds_write_b128 per 8 values (the round-5 layout wrote 8-byte halves,
+//    2-way bank conflicts on every store), and that unit is the next stage's B operand as it stands.
+//  * CONVERSION BEFORE THE BARRIER.  bias / ReLU / fp16 conversion / mask building run on registers before the barrier
+//    that ends the stage's LDS reads: the four waves that finish their K loop first (the older wave of each SIMD owns the
+//    matrix pipe) convert in the shadow of their partners' MFMAs; after the barrier only the stores are left.
+//  * ReLU masks are the SIGN BITS of the fp16 pre-activations, shifted into 128 bits per lane and layer and applied to
+//    the packed fp16 gradients (ReLU'(+0) = 1 instead of 0: a unit at exactly zero has a zero incoming row or measure zero).
+//  * d sdf / d xyz through lin4 comes out of the matrix pipe (rows m..m+2 of the transposed stage carry lin4's xyz columns).
+// Stage list, latent folding, lin4^T latent partial parked in the J rows and the fp16 range guard are those of
+// hm_decoder_h.hip (reference: deepsdf/networks/deep_sdf_decoder.py:75-110, wild_completion/utils.py:112-193,
+// loss.py:229-241).
 #include <stdlib.h>
 
 #include "hm_common.h"
 #include "hm_internal.h"
+#include "hm_gemm_p.h"
 
 using namespace hm;
+using namespace hm_p;
 
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
-
-constexpr int TQP = 128;       // queries per workgroup tile
-constexpr int NQB = 4;         // 32-query blocks per tile
-constexpr int NWP = 8;         // waves per workgroup (two per SIMD)
-constexpr int NRB = 2;         // 32-row blocks per wave: w, w + 8
 
 struct DecodeArgsP {
   DecoderDev dec;
@@ -56,120 +64,85 @@ __device__ __forceinline__ f32x16 zero16p() {
   return z;
 }
 
-__device__ __forceinline__ void store4(f16x4* x4, int idx, const float (&v)[4]) {
-  f16x4 h;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) h[j] = (_Float16)v[j];
-  x4[idx] = h;
-}
+// X unit u = 2 t + h of query q holds rows 16 t + 4 h + {0..3} (elements 0..3) and 16 t + 8 + 4 h + {0..3} (elements 4..7)
+__device__ __forceinline__ int unit_row0(int u) { return 16 * (u >> 1) + 4 * (u & 1); }
 
-struct ASetP { f16x8 r[NRB]; };
-struct BSetP { f16x8 q[NQB]; };
-
-#define HM_MFMA(A, B, C) C = __builtin_amdgcn_mfma_f32_32x32x16_f16(A, B, C, 0, 0, 0)
-#define HM_FENCE() __builtin_amdgcn_sched_barrier(0)
-
-// One K-step (16 k): 8 MFMAs (4 when only one of the wave's row blocks is valid in this stage), ordered by query block
-// so that each B operand dies after its second use and is REFILLED IN PLACE for the next step right there (the read
-// lands ~6 MFMAs = 200+ cycles before its first use): one B set instead of a ring of two -- with 128 accumulator and
-// 32 mask registers per lane there is no room for a second.  The weight fetch for two steps on rides in the last gaps.
-template <bool U0, bool U1>
-__device__ __forceinline__ void step_p(f32x16 (&acc)[NRB][NQB], const ASetP& a, BSetP& b, ASetP& an,
-                                       const f16x8* __restrict__ wp0, const f16x8* __restrict__ wp1, int ka,
-                                       const f16x8* xp, int kb, int xo) {
-  const f16x8* ph = xp + kb * 2 * TQP + xo;
-  HM_FENCE();
-#pragma unroll
-  for (int nb = 0; nb < NQB; ++nb) {
-    if (U0) HM_MFMA(a.r[0], b.q[nb], acc[0][nb]);
-    if (U1) HM_MFMA(a.r[1], b.q[nb], acc[1][nb]);
-    HM_FENCE();
-    b.q[nb] = ph[32 * nb];
-    if (nb == 2 && U0) an.r[0] = wp0[ka * 128];
-    if (nb == 3 && U1) an.r[1] = wp1[ka * 128];
-    if (nb == 3 && U0 && !U1) {}
-    HM_FENCE();
-  }
-}
-
-template <bool U0, bool U1, bool DRAIN>
-__device__ __forceinline__ void gemm_loop_p(f32x16 (&acc)[NRB][NQB], const f16x8* __restrict__ wp0,
-                                            const f16x8* __restrict__ wp1, int n_k16, const f16x8* xp) {
-  // The lane id is re-derived HERE (volatile asm: not CSE'd with the kernel's copy) so that the LDS read pointer of the
-  // loop is computed in its preheader instead of being reloaded from a spill slot: a scratch reload still in flight
-  // at loop entry makes hipcc's wait-count pass put s_waitcnt vmcnt(0) in front of the first ds_read of EVERY
-  // iteration, which drains the weight prefetch ring (effective prefetch distance: one K-step).
-  int lane;
-  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
-  const int xo = (lane >> 5) * TQP + (lane & 31);
-  const int last = n_k16 - 1;
-  ASetP a0 = {}, a1 = {}, a2 = {};
-  BSetP bq;
-  if (DRAIN) {   // forward-only kernel: something (a scalar load) is still pending here and poisons the loop head the
-    __builtin_amdgcn_s_waitcnt(0x0070);   // same way; draining once (vmcnt(0) lgkmcnt(0), gfx9 encoding) is free there.
-    HM_FENCE();                           // In the fwd+bwd kernel the drain would wait for epilogue stores: left out.
-  }
-  auto lda = [&](ASetP& a, int k) {
-    k = k < last ? k : last;
-    if (U0) a.r[0] = wp0[k * 128];
-    if (U1) a.r[1] = wp1[k * 128];
-  };
-  lda(a0, 0); lda(a1, 1);
-#pragma unroll
-  for (int i = 0; i < NQB; ++i) bq.q[i] = xp[xo + 32 * i];
-#define HM_STEPP(AS, ANEXT, I)                                                                              \
-  if (HM_COND(I)) {                                                                                         \
-    step_p<U0, U1>(acc, AS, bq, ANEXT, wp0, wp1, (ks + (I) + 2 < n_k16) ? ks + (I) + 2 : last, xp,          \
-                   (ks + (I) + 1 < n_k16) ? ks + (I) + 1 : last, xo);                                       \
-  }
-  // groups of three run branch-free (statically named ring sets => counted vmcnt / lgkmcnt waits, no register rotation)
-  int ks = 0;
-#define HM_COND(I) true
-  for (; ks + 3 <= n_k16; ks += 3) {
-    HM_STEPP(a0, a2, 0)
-    HM_STEPP(a1, a0, 1)
-    HM_STEPP(a2, a1, 2)
-  }
-#undef HM_COND
-#define HM_COND(I) (ks + (I) < n_k16)
-  if (ks < n_k16) {
-    HM_STEPP(a0, a2, 0)
-    HM_STEPP(a1, a0, 1)
-  }
-#undef HM_COND
-#undef HM_STEPP
-}
-
-// X[k][q] as float for k = 8*grp + j (VALU side paths)
-__device__ __forceinline__ void load_group_p(const f16x8* xp, int grp, int q, float (&x)[8]) {
-  const f16x8 h = xp[grp * TQP + q];
+__device__ __forceinline__ void load_unit_p(const f16x8* xp, int u, int q, float (&x)[8]) {
+  const f16x8 h = xp[u * TQP + q];
 #pragma unroll
   for (int j = 0; j < 8; ++j) x[j] = (float)h[j];
 }
 
-// ReLU masks: 128 bits per lane and layer (2 row blocks x 4 query blocks x 16 accumulator registers)
-struct Mask { uint32_t w[4]; };   // w[2 * r + (nb >> 1)], bit (nb & 1) * 16 + reg
+// Zero the fp16 halves of d whose ReLU-mask bit says "was negative".  word: the mask word of the block, s: position of
+// dword i of unit p of query block nb in it (see Mask): the sign of the low / high half sits at bit s / 16 + s.
+__device__ __forceinline__ uint32_t apply_mask_p(uint32_t d, uint32_t word, int s) {
+  const uint32_t t = word << (15 - s);
+  const s16x2 neg = __builtin_bit_cast(s16x2, t) >> 15;       // 0xffff per half where masked
+  return d & ~__builtin_bit_cast(uint32_t, neg);
+}
 
-// Shader-clock stamps of wave 0 of workgroup 0 (hm_debug_set_k1p_trace, scripts/gpu_trace_k1p.py), per stage s:
-// [5 s + 0] stage entered (after the X barrier), +1 K loop starts, +2 K loop done, +3 barrier passed, +4 epilogue done.
-// Compiled in only with -DHM_K1P_TRACE: even switched off at run time the stamps cost 3 % of the launch (more live
-// values, different spills), stamps of every wave 8 %.
+__device__ __forceinline__ bool guard_tripped_p(const f16x8 gmax, const f16x8 gmin) {
+  bool bad = false;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) bad = bad || !((float)gmax[e] < 65504.f) || !((float)gmin[e] > -65504.f);
+  return bad;
+}
+
+// The converted units of a block wait for the barrier INSIDE the block's accumulator registers (unit p in elements
+// 4 p .. 4 p + 3, as bits): no register beyond the accumulators is held across the barrier.  Unit p is formed from
+// elements 8 p .. 8 p + 7, so p = 0 is converted first.
+__device__ __forceinline__ void stash_unit_p(f32x16& acc, int p, const f16x8 h) {
+  const u32x4 d = __builtin_bit_cast(u32x4, h);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { const uint32_t t = d[i]; acc[4 * p + i] = __uint_as_float(t); }   // (__builtin_bit_cast applied
+                                               // to a vector ELEMENT reads element 0 whatever the index: hipcc 7.2; go through a scalar)
+}
+__device__ __forceinline__ f16x8 stashed_unit_p(const f32x16& acc, int p) {
+  u32x4 d;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { const float f = acc[4 * p + i]; d[i] = __float_as_uint(f); }
+  return __builtin_bit_cast(f16x8, d);
+}
+
+// ReLU masks: 128 bits per lane and layer.  Word 2 r + (nb >> 1); with D_0..D_7 the eight dwords (fp16 pairs) of the
+// block (r, nb) in store order (D = 4 p + dword of unit p): the sign of D_i's low / high half sits at bit s / 16 + s,
+// s = i + 8 (nb & 1).  Built by the chain m = (m >> 1) | (D & 0x80008000) over nb even (i = 0..7) then nb odd (i = 0..7).
+struct Mask { uint32_t w[4]; };
+
+// Shader-clock stamps of the 8 waves of workgroup 0 (80 slots per wave; hm_debug_set_k1p_trace, scripts/gpu_trace_k1p.py),
+// per stage s: [5 s + 0] stage entered (after the X barrier), +1 K loop starts, +2 K loop done, +3 conversion done and
+// barrier passed, +4 stores done.  Compiled in only with -DHM_K1P_TRACE.
 __device__ long long* g_k1p_trace = nullptr;
 #ifdef HM_K1P_TRACE
-#define HM_STAMP(SLOT) if (trc) g_k1p_trace[SLOT] = clock64()
+#define HM_STAMP(SLOT) if (trc) g_k1p_trace[80 * w + (SLOT)] = clock64()
 #else
 #define HM_STAMP(SLOT)
+#endif
+
+// -DHM_K1P_DEBUG: hm_debug_set_k1p_probe(stage, row) makes the kernel return X[row][.] as stored by that stage instead of
+// the sdf (scripts/gpu_probe_k1p.py compares it with a numpy forward pass layer by layer).  Development builds only.
+#ifdef HM_K1P_DEBUG
+__device__ int g_k1p_probe[2] = {-1, 0};
 #endif
 
 #define HM_MASK_CASES(OP) \
   case 0: OP(mk0); break; case 1: OP(mk1); break; case 2: OP(mk2); break; case 3: OP(mk3); break; \
   case 4: OP(mk4); break; case 5: OP(mk5); break; case 6: OP(mk6); break; default: OP(mk7); break;
 
+#ifndef HM_P_AHEAD_FWD
+#define HM_P_AHEAD_FWD 3         // forward-only kernel: three K-steps ahead (same-box A/B: 1 / 2 / 3 within 1 %)
+#endif
+#ifndef HM_P_AHEAD_BWD
+#define HM_P_AHEAD_BWD 1         // forward + backward kernel: one step ahead -- 8 instead of 24 registers across the epilogues
+#endif
+
 template <int MODE, int TAG>
 __global__ __launch_bounds__(512, 2) void k_decoder_p(const DecodeArgsP a) {
-  __shared__ f16x8 xp[64 * TQP];   // 128 KiB: X[k/8][q][8], fp16
-  __shared__ float sc[3072];       // 12 KiB scratch: xyz weight columns / lin8 partials + dy / final xyz-gradient sums
-  __shared__ float bl[9 * HID];    // 18 KiB: biases of the 8 forward stages (per-instance c0 / c4 included) + lin8's row
+  constexpr int AH = MODE == 0 ? HM_P_AHEAD_FWD : HM_P_AHEAD_BWD;
+  __shared__ f16x8 xp[64 * TQP];   // 128 KiB: X[unit][q][8], fp16
+  __shared__ float sc[3072];       // 12 KiB scratch: the tile's xyz (forward) / xyz weight columns / lin8 partials + dy / final xyz-gradient sums
+  __shared__ float bl[9 * HID];    // 18 KiB: biases of the 8 forward stages (per-instance c0 / c4 included) + lin8's row;
+                                   // after the forward stages bl[0 .. 3 * TQP) takes d sdf / d xyz through lin4
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -185,26 +158,45 @@ __global__ __launch_bounds__(512, 2) void k_decoder_p(const DecodeArgsP a) {
   const size_t qbase = (size_t)b * a.n_stride + q0;
   const int qa = lane & 31;
   const int hi = lane >> 5;
+  const int xo = hi * TQP + qa;
   const f32x4* pts4 = reinterpret_cast<const f32x4*>(a.pts);
-  f16x4* xp4 = reinterpret_cast<f16x4*>(xp);
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  const f16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
 
-  // stage 0 input: rows 0..2 = xyz, rows 3..15 = 0 (groups 0 and 1); queries past the end of the instance read as 0
+  // the wave's weight stream; the ring is primed with the first three K-steps before anything else
+  WStreamP ws;
+  {
+    const int stream_bytes = a.dec.ps_steps * 2048;
+    char* base = const_cast<char*>(static_cast<const char*>(a.dec.ps)) + (size_t)w * stream_bytes;
+    ws.rs = __builtin_amdgcn_make_buffer_rsrc(base, 0, stream_bytes, 0x00020000);
+    ws.v0 = lane * 16; ws.v1 = lane * 16 + 1024;
+  }
+  int sq = 0;                      // byte position of the current stage's step 0 in the stream
+  ASetP a0, a1, a2, a3;
+  a0.r[0] = wload_p(ws, 0, 0);    a0.r[1] = wload_p(ws, 1, 0);
+  a1.r[0] = zero8; a1.r[1] = zero8; a2.r[0] = zero8; a2.r[1] = zero8; a3.r[0] = zero8; a3.r[1] = zero8;
+  if (AH >= 2) { a1.r[0] = wload_p(ws, 0, 2048); a1.r[1] = wload_p(ws, 1, 2048); }
+  if (AH >= 3) { a2.r[0] = wload_p(ws, 0, 4096); a2.r[1] = wload_p(ws, 1, 4096); }
+
+  // stage 0 input: rows 0..2 = xyz (unit 0, elements 0..2), every other row of the padded K-steps 0..3 (units 0..7) = 0;
+  // queries past the end of the instance read as 0.  The tile's xyz also waits in sc for lin3's splice.
   if (tid < TQP) {
     const f32x4 p = tid < cnt ? pts4[qbase + tid] : zero4;
-    const float v0[4] = {p[0], p[1], p[2], 0.f};
-    const float vz[4] = {0.f, 0.f, 0.f, 0.f};
-    store4(xp4, (0 * TQP + tid) * 2 + 0, v0);
-    store4(xp4, (0 * TQP + tid) * 2 + 1, vz);
-    store4(xp4, (1 * TQP + tid) * 2 + 0, vz);
-    store4(xp4, (1 * TQP + tid) * 2 + 1, vz);
+    f16x8 u0 = zero8;
+    u0[0] = (_Float16)p[0]; u0[1] = (_Float16)p[1]; u0[2] = (_Float16)p[2];
+    xp[tid] = u0;
+#pragma unroll
+    for (int i = 1; i < 8; ++i) xp[i * TQP + tid] = zero8;
+    sc[0 * TQP + tid] = p[0]; sc[1 * TQP + tid] = p[1]; sc[2 * TQP + tid] = p[2];
   }
 
   Mask mk0 = {}, mk1 = {}, mk2 = {}, mk3 = {}, mk4 = {}, mk5 = {}, mk6 = {}, mk7 = {};
   f32x16 acc[NRB][NQB];
-  float gx[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};     // d sdf / d xyz of queries (lane, lane + 64), this wave's share
+  float gx[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};     // d sdf / d xyz through lin0 of queries (lane, lane + 64), this wave's share
   float y_keep = 0.f;
-  float xmax = 0.f;                                         // fp16 range guard, see hm_decoder_h.hip
+  // fp16 range guard (see hm_decoder_h.hip), kept on the PACKED fp16 values that go to X: largest stored activation /
+  // gradient and smallest gradient; a tile in which one of them reaches fp16's largest finite value (or inf) is poisoned
+  f16x8 gmax = zero8, gmin = zero8;
   const float* cbias0 = a.c0 + (size_t)b * HID;
   const float* cbias4 = a.c4 + (size_t)b * HID;
   bl[8 * HID + tid] = a.dec.w8[tid];
@@ -215,33 +207,39 @@ __global__ __launch_bounds__(512, 2) void k_decoder_p(const DecodeArgsP a) {
   }
 
   constexpr int n_stage = MODE == 0 ? 8 : NSTAGE;
+  const int mbx = m >> 5;          // lin3's rows m..m+2 (always rows 29..31 of their block: m = 509 - L, L % 32 == 0) carry xyz
   for (int s = 0; s < n_stage; ++s) {
     const StageDesc& sd = a.dec.st[s];
-    const StageDescH& sh = a.dec.sth[s];
     const int epi = sd.epi;
+    const int n_grp = a.dec.pgrp[s];
+    // the wave's two 32-row blocks of this stage: w and w + 8, swapped in stages whose valid blocks all lie in the upper
+    // half (lin0's transpose) so that a wave with ONE valid block always has it in slot 0: two K-loop variants, not three
+    const int sw8 = a.dec.pswap[s] * 8;
+    const int mbr[NRB] = {w + sw8, w + 8 - sw8};
     bool u[NRB];
 #pragma unroll
-    for (int r = 0; r < NRB; ++r) u[r] = (w + 8 * r >= sd.mb_lo) && (w + 8 * r < sd.mb_hi);
-    const float us = sh.unscale;
+    for (int r = 0; r < NRB; ++r) u[r] = (mbr[r] >= sd.mb_lo) && (mbr[r] < sd.mb_hi);
+    const float us = a.dec.pus[s];
     __syncthreads();
 #ifdef HM_K1P_TRACE
-    const bool trc = g_k1p_trace != nullptr && blockIdx.x == 0 && tid == 0;
+    const bool trc = g_k1p_trace != nullptr && blockIdx.x == 0 && lane == 0;
 #endif
     HM_STAMP(5 * s + 0);
 
-    if (MODE == 1 && (epi == EPI_BWD4 || epi == EPI_BWD0)) {
-      // xyz columns of lin4 / lin0 (512 x 4) through LDS scratch, then this wave's 64 rows against both query halves
-      reinterpret_cast<f32x4*>(sc)[tid] = reinterpret_cast<const f32x4*>(epi == EPI_BWD4 ? a.dec.w4x : a.dec.w0x)[tid];
+    if (MODE == 1 && epi == EPI_BWD0) {
+      // xyz columns of lin0 (512 x 4) through LDS scratch, then this wave's 64 rows (units 8 w .. 8 w + 7) against both query halves
+      reinterpret_cast<f32x4*>(sc)[tid] = reinterpret_cast<const f32x4*>(a.dec.w0x)[tid];
       __syncthreads();
       const f32x4* wx = reinterpret_cast<const f32x4*>(sc);
 #pragma unroll 2
       for (int g = 0; g < 8; ++g) {
         float xa[8], xb[8];
-        load_group_p(xp, 8 * w + g, lane, xa);
-        load_group_p(xp, 8 * w + g, lane + 64, xb);
+        load_unit_p(xp, 8 * w + g, lane, xa);
+        load_unit_p(xp, 8 * w + g, lane + 64, xb);
+        const int r0 = unit_row0(8 * w + g);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          const f32x4 wv = wx[64 * w + 8 * g + j];
+          const f32x4 wv = wx[r0 + (j < 4 ? j : j + 4)];
           gx[0][0] = fmaf(xa[j], wv[0], gx[0][0]); gx[0][1] = fmaf(xa[j], wv[1], gx[0][1]); gx[0][2] = fmaf(xa[j], wv[2], gx[0][2]);
           gx[1][0] = fmaf(xb[j], wv[0], gx[1][0]); gx[1][1] = fmaf(xb[j], wv[1], gx[1][1]); gx[1][2] = fmaf(xb[j], wv[2], gx[1][2]);
         }
@@ -258,7 +256,7 @@ __global__ __launch_bounds__(512, 2) void k_decoder_p(const DecodeArgsP a) {
 #pragma unroll
       for (int r = 0; r < NRB; ++r) {
         if (!u[r]) continue;
-        const int jz = (w + 8 * r - mb_zx) * 32;
+        const int jz = (mbr[r] - mb_zx) * 32;
 #pragma unroll
         for (int nb = 0; nb < NQB; ++nb) {
           const int q = nb * 32 + qa;
@@ -276,111 +274,93 @@ __global__ __launch_bounds__(512, 2) void k_decoder_p(const DecodeArgsP a) {
     }
 
     HM_STAMP(5 * s + 1);
-    {
-      const f16x8* wp = reinterpret_cast<const f16x8*>(sh.wp);
-      const f16x8* wp0 = wp + (size_t)(w - sd.mb_lo) * sh.mb_stride + lane;
-      const f16x8* wp1 = wp + (size_t)(w + 8 - sd.mb_lo) * sh.mb_stride + lane;
-      if (u[0] && u[1]) gemm_loop_p<true, true, MODE == 0>(acc, wp0, wp1, sh.n_k16, xp);
-      else if (u[0]) gemm_loop_p<true, false, MODE == 0>(acc, wp0, wp1, sh.n_k16, xp);
-      else if (u[1]) gemm_loop_p<false, true, MODE == 0>(acc, wp0, wp1, sh.n_k16, xp);
+#ifdef HM_K1P_TRACE
+    long long* gst = (trc && s == 1) ? g_k1p_trace + 640 + 8 * w : nullptr;    // K-loop group stamps of stage 1
+    if (u[0] && u[1]) k_loop_p<true, true, AH>(acc, a0, a1, a2, a3, ws, sq, n_grp, xp, xo, gst);
+    else
+#endif
+    if (u[0] && u[1]) k_loop_p<true, true, AH>(acc, a0, a1, a2, a3, ws, sq, n_grp, xp, xo);
+    else if (u[0]) k_loop_p<true, false, AH>(acc, a0, a1, a2, a3, ws, sq, n_grp, xp, xo);
+    else {   // no valid row block in this stage: keep the ring in step (the next stage's first three steps)
+      const int sn = sq + n_grp * 8192;
+      a0.r[0] = wload_p(ws, 0, sn);        a0.r[1] = wload_p(ws, 1, sn);
+      if (AH >= 2) { a1.r[0] = wload_p(ws, 0, sn + 2048); a1.r[1] = wload_p(ws, 1, sn + 2048); }
+      if (AH >= 3) { a2.r[0] = wload_p(ws, 0, sn + 4096); a2.r[1] = wload_p(ws, 1, sn + 4096); }
     }
+    sq += n_grp * 8192;
+    // the sets beyond the first AH are refilled by the next stage's first steps before anyone reads them: end
+    // their live ranges here (no instruction)
+    asm volatile("" : "=v"(a3.r[0]), "=v"(a3.r[1]));
+    if (AH < 3) asm volatile("" : "=v"(a2.r[0]), "=v"(a2.r[1]));
+    if (AH < 2) asm volatile("" : "=v"(a1.r[0]), "=v"(a1.r[1]));
     HM_STAMP(5 * s + 2);
-    __syncthreads();
-    HM_STAMP(5 * s + 3);
 
+    // ---- conversion on registers (no access to X): unit p of block (r, nb) = the 16 bytes X[2 (2 mb + p) + hi][nb * 32 + qa] ----
+    bool st_x[NRB] = {false, false};
+#ifdef ABL_NOEPI       // timing ablation (wrong results): K loops and barriers only
+#pragma unroll
+    for (int r = 0; r < NRB; ++r)
+#pragma unroll
+      for (int nb = 0; nb < NQB; ++nb) asm volatile("" :: "v"(acc[r][nb]));
+    if (false) {
+#else
     if (MODE == 0 || epi <= EPI_FWD7) {
+#endif
       const float* bias = bl + s * HID;
       Mask mk = {};
-      // lin3's rows m..m+2 (always rows 29..31 of their block: m = 509 - L, L % 32 == 0) carry xyz into the skip layer
-      const int mbx = m >> 5;
+      const f32x8 us8 = {us, us, us, us, us, us, us, us};
 #pragma unroll
       for (int r = 0; r < NRB; ++r) {
         if (!u[r]) continue;
-        const int mb = w + 8 * r;
+        st_x[r] = true;
+        const int mb = mbr[r];
         f32x4 bv[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) bv[g] = *reinterpret_cast<const f32x4*>(bias + mb * 32 + 8 * g + 4 * hi);
 #pragma unroll
-        for (int nb = 0; nb < NQB; ++nb) {
-          uint32_t bits = 0;
+        for (int half = 0; half < 2; ++half) {
+          uint32_t chain = 0;
 #pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            const int f4 = mb * 32 + 8 * g + 4 * hi;
-            float v[4];
+          for (int nbi = 0; nbi < 2; ++nbi) {
+            const int nb = 2 * half + nbi;
+            // per unit p (accumulator elements 8 p .. 8 p + 7): four packed fmas (scale, bias), four packed conversions, [mask
+            // chain], four packed ReLUs, four packed range-guard maxima (four independent chains); the unit lands in
+            // elements 4 p .. 4 p + 3
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              const float val = fmaf(acc[r][nb][4 * g + j], us, bv[g][j]);
-              const bool pos = val > 0.f;
-              bits |= (pos ? 1u : 0u) << (4 * g + j);
-              v[j] = pos ? val : 0.f;
+            for (int p = 0; p < 2; ++p) {
+              f32x8 av, bb;
+#pragma unroll
+              for (int e = 0; e < 8; ++e) { av[e] = acc[r][nb][8 * p + e]; bb[e] = bv[2 * p + (e >> 2)][e & 3]; }
+              f16x8 h = __builtin_convertvector(__builtin_elementwise_fma(av, us8, bb), f16x8);
+              if (MODE == 1) {
+                const u32x4 d = __builtin_bit_cast(u32x4, h);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) chain = (chain >> 1) | (d[i] & 0x80008000u);
+              }
+              h = __builtin_elementwise_max(h, zero8);
+              gmax = __builtin_elementwise_max(gmax, h);
+              stash_unit_p(acc[r][nb], p, h);
             }
-            xmax = fmaxf(xmax, fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])));
-            if (g == 3 && epi == EPI_FWD3 && mb == mbx && hi == 1) {
-              const int q = nb * 32 + qa;
-              const f32x4 p = q < cnt ? pts4[qbase + q] : zero4;
-              v[1] = p[0]; v[2] = p[1]; v[3] = p[2];
-            }
-            store4(xp4, ((f4 >> 3) * TQP + nb * 32 + qa) * 2 + hi, v);
+            HM_FENCE();       // keep the program order
           }
-          mk.w[2 * r + (nb >> 1)] |= bits << ((nb & 1) * 16);
+          mk.w[2 * r + half] = chain;
+        }
+        if (epi == EPI_FWD3 && mb == mbx && hi == 1) {
+          // lin3's rows m..m+2 (rows 29..31 of this block: elements 5..7 of unit 1 of the upper lane half) carry xyz into the skip layer
+#pragma unroll
+          for (int nb = 0; nb < NQB; ++nb) {
+            const int q = nb * 32 + qa;
+            const f16x2 x01 = {(_Float16)0, (_Float16)sc[0 * TQP + q]};
+            const f16x2 x23 = {(_Float16)sc[1 * TQP + q], (_Float16)sc[2 * TQP + q]};
+            const uint32_t d2 = (__float_as_uint(acc[r][nb][6]) & 0x0000ffffu) | (__builtin_bit_cast(uint32_t, x01) & 0xffff0000u);
+            acc[r][nb][6] = __uint_as_float(d2);
+            acc[r][nb][7] = __uint_as_float(__builtin_bit_cast(uint32_t, x23));
+          }
         }
       }
 #define HM_SET(M) M = mk
       if (MODE == 1) switch (sd.layer) { HM_MASK_CASES(HM_SET) }
 #undef HM_SET
-
-      if (epi == EPI_FWD7) {
-        __syncthreads();
-        float pa = 0.f, pb = 0.f;
-#pragma unroll 2
-        for (int g = 0; g < 8; ++g) {
-          float xa[8], xb[8];
-          load_group_p(xp, 8 * w + g, lane, xa);
-          load_group_p(xp, 8 * w + g, lane + 64, xb);
-          const f32x4 w0 = *reinterpret_cast<const f32x4*>(bl + 8 * HID + 64 * w + 8 * g);
-          const f32x4 w1 = *reinterpret_cast<const f32x4*>(bl + 8 * HID + 64 * w + 8 * g + 4);
-#pragma unroll
-          for (int j = 0; j < 4; ++j) { pa = fmaf(xa[j], w0[j], pa); pb = fmaf(xb[j], w0[j], pb); }
-#pragma unroll
-          for (int j = 0; j < 4; ++j) { pa = fmaf(xa[4 + j], w1[j], pa); pb = fmaf(xb[4 + j], w1[j], pb); }
-        }
-        if (__any(!(xmax < 65504.f))) { pa = __builtin_nanf(""); pb = pa; }
-        sc[w * TQP + lane] = pa;
-        sc[w * TQP + 64 + lane] = pb;
-        __syncthreads();
-        if (tid < TQP) {
-          float a8 = 0.f;
-#pragma unroll
-          for (int i = 0; i < NWP; ++i) a8 += sc[i * TQP + tid];
-          a8 += a.dec.b8;
-          const float yv = tanhf(a8);
-          y_keep = yv;
-          if (tid < cnt) a.y[qbase + tid] = yv;
-          sc[NWP * TQP + tid] = 1.f - yv * yv;
-        }
-        if (MODE == 0) return;
-        __syncthreads();
-        float dy[NQB];
-#pragma unroll
-        for (int nb = 0; nb < NQB; ++nb) dy[nb] = sc[NWP * TQP + nb * 32 + qa];
-#pragma unroll
-        for (int r = 0; r < NRB; ++r) {
-          const int mb = w + 8 * r;
-#pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            const int f4 = mb * 32 + 8 * g + 4 * hi;
-            const f32x4 wv = *reinterpret_cast<const f32x4*>(bl + 8 * HID + f4);
-#pragma unroll
-            for (int nb = 0; nb < NQB; ++nb) {
-              const uint32_t bits = mk.w[2 * r + (nb >> 1)] >> ((nb & 1) * 16);
-              float v[4];
-#pragma unroll
-              for (int j = 0; j < 4; ++j) v[j] = ((bits >> (4 * g + j)) & 1u) ? dy[nb] * wv[j] : 0.f;
-              store4(xp4, ((f4 >> 3) * TQP + nb * 32 + qa) * 2 + hi, v);
-            }
-          }
-        }
-      }
     } else if (MODE == 1 && (epi == EPI_BWD || epi == EPI_BWD4)) {
       Mask mk;
 #define HM_GET(M) mk = M
@@ -389,7 +369,7 @@ __global__ __launch_bounds__(512, 2) void k_decoder_p(const DecodeArgsP a) {
 #pragma unroll
       for (int r = 0; r < NRB; ++r) {
         if (!u[r]) continue;
-        const int mb = w + 8 * r;
+        const int mb = mbr[r];
         if (epi == EPI_BWD4 && mb >= mb_zx) {      // latent rows: park in J (same thread re-reads them in BWD0)
           const int jz = (mb - mb_zx) * 32;
 #pragma unroll
@@ -408,25 +388,42 @@ __global__ __launch_bounds__(512, 2) void k_decoder_p(const DecodeArgsP a) {
           }
           continue;
         }
+        st_x[r] = true;
+        const bool xyz_rows = epi == EPI_BWD4 && mb == mbx && hi == 1;
+        const f32x8 us8 = {us, us, us, us, us, us, us, us};
 #pragma unroll
         for (int nb = 0; nb < NQB; ++nb) {
-          const uint32_t bits = mk.w[2 * r + (nb >> 1)] >> ((nb & 1) * 16);
-#pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            const int f4 = mb * 32 + 8 * g + 4 * hi;
-            float v[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = ((bits >> (4 * g + j)) & 1u) ? acc[r][nb][4 * g + j] * us : 0.f;
-            xmax = fmaxf(xmax, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
-            store4(xp4, ((f4 >> 3) * TQP + nb * 32 + qa) * 2 + hi, v);
+          const uint32_t word = mk.w[2 * r + (nb >> 1)];
+          if (xyz_rows) {
+            // rows m..m+2 of lin4's transpose (elements 13..15): d sdf / d xyz through lin4 (no mask: inputs, not ReLU outputs)
+            const int q = nb * 32 + qa;
+            bl[0 * TQP + q] = acc[r][nb][13] * us; bl[1 * TQP + q] = acc[r][nb][14] * us; bl[2 * TQP + q] = acc[r][nb][15] * us;
           }
+#pragma unroll
+          for (int p = 0; p < 2; ++p) {
+            f32x8 av;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) av[e] = acc[r][nb][8 * p + e];
+            const f16x8 h = __builtin_convertvector(av * us8, f16x8);
+            gmax = __builtin_elementwise_max(gmax, h);
+            gmin = __builtin_elementwise_min(gmin, h);
+            u32x4 d = __builtin_bit_cast(u32x4, h);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) d[i] = apply_mask_p(d[i], word, 4 * p + i + 8 * (nb & 1));
+            stash_unit_p(acc[r][nb], p, __builtin_bit_cast(f16x8, d));
+          }
+          if (xyz_rows) {   // the three xyz rows are no activations of lin3: zero in X (lin3's transpose has zero columns there anyway)
+            acc[r][nb][6] = __uint_as_float(__float_as_uint(acc[r][nb][6]) & 0x0000ffffu);
+            acc[r][nb][7] = 0.f;
+          }
+          HM_FENCE();
         }
       }
     } else if (MODE == 1) {  // EPI_BWD0
 #pragma unroll
       for (int r = 0; r < NRB; ++r) {
         if (!u[r]) continue;
-        const int jz = (w + 8 * r - mb_zx) * 32;
+        const int jz = (mbr[r] - mb_zx) * 32;
 #pragma unroll
         for (int nb = 0; nb < NQB; ++nb) {
           const int q = nb * 32 + qa;
@@ -443,11 +440,93 @@ __global__ __launch_bounds__(512, 2) void k_decoder_p(const DecodeArgsP a) {
         }
       }
     }
+
+    __syncthreads();               // every wave is done reading X
+    HM_STAMP(5 * s + 3);
+#pragma unroll
+    for (int r = 0; r < NRB; ++r) {
+      if (!st_x[r]) continue;
+      const int mb = mbr[r];
+#pragma unroll
+      for (int nb = 0; nb < NQB; ++nb)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) xp[(2 * (2 * mb + p) + hi) * TQP + nb * 32 + qa] = stashed_unit_p(acc[r][nb], p);
+    }
     HM_STAMP(5 * s + 4);
+#ifdef HM_K1P_DEBUG
+    if (g_k1p_probe[0] == s) {
+      __syncthreads();
+      const int row = g_k1p_probe[1];
+      const int t16 = row >> 4, rr = row & 15;
+      const int hh = (rr >> 2) & 1, e = (rr & 3) + 4 * (rr >> 3);
+      if (tid < cnt) a.y[qbase + tid] = (float)xp[(2 * t16 + hh) * TQP + tid][e];
+      return;
+    }
+#endif
+
+    if (epi == EPI_FWD7) {
+      __syncthreads();
+      float pa = 0.f, pb = 0.f;
+#pragma unroll 2
+      for (int g = 0; g < 8; ++g) {
+        float xa[8], xb[8];
+        load_unit_p(xp, 8 * w + g, lane, xa);
+        load_unit_p(xp, 8 * w + g, lane + 64, xb);
+        const int r0 = unit_row0(8 * w + g);
+        const f32x4 w0 = *reinterpret_cast<const f32x4*>(bl + 8 * HID + r0);
+        const f32x4 w1 = *reinterpret_cast<const f32x4*>(bl + 8 * HID + r0 + 8);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { pa = fmaf(xa[j], w0[j], pa); pb = fmaf(xb[j], w0[j], pb); }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { pa = fmaf(xa[4 + j], w1[j], pa); pb = fmaf(xb[4 + j], w1[j], pb); }
+      }
+      if (__any(guard_tripped_p(gmax, gmin))) { pa = __builtin_nanf(""); pb = pa; }
+      sc[w * TQP + lane] = pa;
+      sc[w * TQP + 64 + lane] = pb;
+      __syncthreads();
+      if (tid < TQP) {
+        float a8 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NWP; ++i) a8 += sc[i * TQP + tid];
+        a8 += a.dec.b8;
+        const float yv = tanhf(a8);
+        y_keep = yv;
+        if (tid < cnt) a.y[qbase + tid] = yv;
+        sc[NWP * TQP + tid] = 1.f - yv * yv;
+      }
+      if (MODE == 0) return;
+      __syncthreads();
+      // backward seed: G7 = mask7 . (dy w8), straight into X (every wave's lin8 reads are behind the barriers above)
+      float dy[NQB];
+#pragma unroll
+      for (int nb = 0; nb < NQB; ++nb) dy[nb] = sc[NWP * TQP + nb * 32 + qa];
+#pragma unroll
+      for (int r = 0; r < NRB; ++r) {
+        const int mb = mbr[r];
+#pragma unroll
+        for (int nb = 0; nb < NQB; ++nb) {
+          const uint32_t word = mk7.w[2 * r + (nb >> 1)];
+#pragma unroll
+          for (int p = 0; p < 2; ++p) {
+            f16x8 h;
+#pragma unroll
+            for (int gg = 0; gg < 2; ++gg) {
+              const f32x4 wv = *reinterpret_cast<const f32x4*>(bl + 8 * HID + mb * 32 + 8 * (2 * p + gg) + 4 * hi);
+#pragma unroll
+              for (int j = 0; j < 4; ++j) h[4 * gg + j] = (_Float16)(dy[nb] * wv[j]);
+            }
+            u32x4 d = __builtin_bit_cast(u32x4, h);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) d[i] = apply_mask_p(d[i], word, 4 * p + i + 8 * (nb & 1));
+            xp[(2 * (2 * mb + p) + hi) * TQP + nb * 32 + qa] = __builtin_bit_cast(f16x8, d);
+          }
+        }
+      }
+    }
   }
 
   if (MODE == 0) return;
-  if (__any(!(xmax < 65504.f))) { gx[0][0] = __builtin_nanf(""); gx[1][0] = gx[0][0]; }
+  if (__any(guard_tripped_p(gmax, gmin))) { gx[0][0] = __builtin_nanf(""); gx[1][0] = gx[0][0]; }
   __syncthreads();
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
@@ -456,7 +535,7 @@ __global__ __launch_bounds__(512, 2) void k_decoder_p(const DecodeArgsP a) {
   }
   __syncthreads();
   if (tid < cnt) {
-    float g0 = 0.f, g1 = 0.f, g2 = 0.f;
+    float g0 = bl[0 * TQP + tid], g1 = bl[1 * TQP + tid], g2 = bl[2 * TQP + tid];     // through lin4 (matrix pipe)
 #pragma unroll
     for (int i = 0; i < NWP; ++i) {
       g0 += sc[(i * 3 + 0) * TQP + tid];
@@ -477,6 +556,13 @@ __global__ __launch_bounds__(512, 2) void k_decoder_p(const DecodeArgsP a) {
 }
 
 }  // namespace
+
+#ifdef HM_K1P_DEBUG
+extern "C" void hm_debug_set_k1p_probe(int stage, int row) {
+  const int v[2] = {stage, row};
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_k1p_probe), v, sizeof(v));
+}
+#endif
 
 extern "C" void hm_debug_set_k1p_trace(long long* d_buf) {
   (void)hipMemcpyToSymbol(HIP_SYMBOL(g_k1p_trace), &d_buf, sizeof(d_buf));

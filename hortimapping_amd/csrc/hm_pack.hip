@@ -87,6 +87,53 @@ size_t pack_stage_h(std::vector<uint16_t>& blob, int mb_lo, int mb_hi, int n_k16
   return off;
 }
 
+
+// Weight streams of the plain-fp16 kernel (hm_decoder_p.hip).  Each of the 8 waves of a workgroup reads ONE contiguous
+// stream in exactly the order it consumes it: [stage][K-step of 16][row block r = 0, 1 -> 32-row block w + 8 r][lane][8
+// halves], the step count of every stage padded to a multiple of 4 with zero steps (the kernel's ring of four operand
+// sets then has the same phase at every stage entry and its prefetch runs across stage boundaries without any address
+// logic).  fp16(A * 2^shift) at the per-stage power-of-two shift of pack_stage_h.  K order inside a step: lane half h holds
+// k = 16 t + 4 h + {0..3} and 16 t + 8 + 4 h + {0..3} -- the rows ONE lane of the 32x32 accumulator layout owns, so the
+// kernel's epilogue writes whole 16-byte activation units (conflict-free) and the B operand of the next stage is that unit.
+// swap[s] = 1 exchanges the two slots (stages with no valid block below 8).  Row blocks outside [mb_lo, mb_hi) are zero (their loads are skipped by the kernel); `slack` zero steps follow the last stage.
+size_t pack_stream_p(std::vector<uint16_t>& blob, const std::function<float(int, int)> (&A)[NSTAGE], const int (&kmax)[NSTAGE],
+                     const int (&lo)[NSTAGE], const int (&hi)[NSTAGE], int (&grp)[NSTAGE], float (&unscale)[NSTAGE],
+                     int (&swap)[NSTAGE], int* steps_out) {
+  int total = 0;
+  for (int s = 0; s < NSTAGE; ++s) { grp[s] = ((kmax[s] + 15) / 16 + 3) / 4; total += 4 * grp[s]; }
+  const int slack = 4;
+  const int T = total + slack;
+  const size_t off = (blob.size() + 63) & ~size_t(63);
+  blob.resize(off + (size_t)NWAVE * T * 2 * 64 * 8, 0);
+  int t0 = 0;
+  for (int s = 0; s < NSTAGE; ++s) {
+    float mx = 0.f;
+    for (int r = lo[s] * 32; r < hi[s] * 32; ++r)
+      for (int c = 0; c < kmax[s]; ++c) mx = fmaxf(mx, fabsf(A[s](r, c)));
+    int shift = 12;
+    while (shift > -12 && ldexpf(mx, shift) >= 32768.f) --shift;
+    unscale[s] = ldexpf(1.f, -shift);
+    swap[s] = lo[s] >= 8 ? 1 : 0;     // every valid block in the upper half: it becomes the wave's slot 0
+    for (int w = 0; w < NWAVE; ++w)
+      for (int t = 0; t < 4 * grp[s]; ++t)
+        for (int rb = 0; rb < 2; ++rb) {
+          const int mb = w + 8 * ((rb + swap[s]) & 1);
+          if (mb < lo[s] || mb >= hi[s]) continue;
+          for (int lane = 0; lane < 64; ++lane)
+            for (int e = 0; e < 8; ++e) {
+              const int r = mb * 32 + (lane & 31);
+              const int c = 16 * t + 8 * (e >> 2) + 4 * (lane >> 5) + (e & 3);
+              const float v = c < kmax[s] ? ldexpf(A[s](r, c), shift) : 0.f;
+              const __half hv = __float2half_rn(v);
+              blob[off + ((((size_t)w * T + t0 + t) * 2 + rb) * 64 + lane) * 8 + e] = *reinterpret_cast<const uint16_t*>(&hv);
+            }
+        }
+    t0 += 4 * grp[s];
+  }
+  *steps_out = T;
+  return off;
+}
+
 }  // namespace
 
 extern "C" int hm_decoder_create(int latent_dim, const float* const* W, const float* const* bias,
@@ -109,8 +156,11 @@ extern "C" int hm_decoder_create(int latent_dim, const float* const* W, const fl
   Pending pend[NSTAGE];
   StageDesc st[NSTAGE];
   memset(st, 0, sizeof(st));
+  std::function<float(int, int)> Afun[NSTAGE];      // kept for the plain-fp16 kernel's weight streams (pack_stream_p)
+  int s_kmax[NSTAGE], s_lo[NSTAGE], s_hi[NSTAGE];
   auto set = [&](int s, int n_kg, int lo, int hi, int epi, int layer, int inst_bias,
                  const std::function<float(int, int)>& A, const std::function<float(int)>* bfun) {
+    Afun[s] = A; s_kmax[s] = n_kg * 8; s_lo[s] = lo; s_hi[s] = hi;
     st[s].n_kg = n_kg; st[s].mb_lo = lo; st[s].mb_hi = hi; st[s].epi = epi; st[s].layer = layer;
     st[s].inst_bias = inst_bias;
     pend[s].wp = pack_stage(blob, lo, hi, n_kg, A);
@@ -176,6 +226,15 @@ extern "C" int hm_decoder_create(int latent_dim, const float* const* W, const fl
     blob.host[o_b4 + f] = bias[4][f];
   }
 
+  // plain-fp16 kernel: the transpose of lin4 also carries lin4's three xyz columns, as rows m..m+2 (the rows the forward
+  // splice puts xyz in): d sdf / d xyz through lin4 then comes out of the matrix pipe with the rest of that stage
+  Afun[11] = [&](int r, int c) {
+    return r < m ? w(4, c, r, HID) : (r < m + 3 ? w(4, c, m + L + (r - m), HID) : (r < m_pad ? 0.f : w(4, c, m + (r - m_pad), HID)));
+  };
+  int pgrp[NSTAGE], pswap[NSTAGE], psteps = 0;
+  float pus[NSTAGE];
+  const size_t poff = pack_stream_p(hblob, Afun, s_kmax, s_lo, s_hi, pgrp, pus, pswap, &psteps);
+
   hm_decoder_s* d = new hm_decoder_s();
   d->L = L;
   d->precision = 0;
@@ -190,6 +249,9 @@ extern "C" int hm_decoder_create(int latent_dim, const float* const* W, const fl
   const float* base = static_cast<const float*>(d->d_blob);
   DecoderDev& dv = d->dev;
   dv.L = L; dv.m = m; dv.m_pad = m_pad; dv.mb_zx = mb_zx;
+  dv.ps = static_cast<const char*>(d->d_blob) + fbytes + poff * sizeof(uint16_t);
+  dv.ps_steps = psteps;
+  for (int s = 0; s < NSTAGE; ++s) { dv.pgrp[s] = pgrp[s]; dv.pus[s] = pus[s]; dv.pswap[s] = pswap[s]; }
   for (int s = 0; s < NSTAGE; ++s) {
     dv.st[s] = st[s];
     dv.st[s].wp = base + pend[s].wp;
