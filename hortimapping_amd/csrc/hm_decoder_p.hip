@@ -51,6 +51,7 @@ struct DecodeArgsP {
   const float* c4;
   float* y;
   float* J;
+  u32x4* mscr;         // forward + backward kernel: ReLU-mask scratch [workgroup][8 layers][512 threads] x 16 bytes
   int n_stride;
   int B;
   int ldJ;
@@ -81,6 +82,16 @@ __device__ __forceinline__ uint32_t apply_mask_p(uint32_t d, uint32_t word, int 
   return d & ~__builtin_bit_cast(uint32_t, neg);
 }
 
+// The lane id, derived afresh (volatile: never hoisted, never merged with an earlier copy).  Everything the epilogues
+// address with -- query column, lane half, LDS / J-row / scratch offsets -- is recomputed from it where it is used, a few
+// VALU instructions per stage; derived once at the top of the kernel, hipcc keeps two dozen such loop-invariant values in
+// registers across all 16 stages (and spills them in the forward + backward kernel).
+__device__ __forceinline__ int fresh_lane_p() {
+  int l;
+  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+  return l;
+}
+
 __device__ __forceinline__ bool guard_tripped_p(const f16x8 gmax, const f16x8 gmin) {
   bool bad = false;
 #pragma unroll
@@ -107,6 +118,9 @@ __device__ __forceinline__ f16x8 stashed_unit_p(const f32x16& acc, int p) {
 // ReLU masks: 128 bits per lane and layer.  Word 2 r + (nb >> 1); with D_0..D_7 the eight dwords (fp16 pairs) of the
 // block (r, nb) in store order (D = 4 p + dword of unit p): the sign of D_i's low / high half sits at bit s / 16 + s,
 // s = i + 8 (nb & 1).  Built by the chain m = (m >> 1) | (D & 0x80008000) over nb even (i = 0..7) then nb odd (i = 0..7).
+// A layer's four words are written to the launch's scratch block by the forward stage and read back by the backward stage
+// that needs them (64 KiB per tile through L2, 16 bytes per thread and stage, issued ahead of the K loop): 4 registers
+// instead of 32 held across the whole tile, which is what lets the forward + backward kernel run without spills.
 struct Mask { uint32_t w[4]; };
 
 // Shader-clock stamps of the 8 waves of workgroup 0 (80 slots per wave; hm_debug_set_k1p_trace, scripts/gpu_trace_k1p.py),
@@ -125,20 +139,26 @@ __device__ long long* g_k1p_trace = nullptr;
 __device__ int g_k1p_probe[2] = {-1, 0};
 #endif
 
-#define HM_MASK_CASES(OP) \
-  case 0: OP(mk0); break; case 1: OP(mk1); break; case 2: OP(mk2); break; case 3: OP(mk3); break; \
-  case 4: OP(mk4); break; case 5: OP(mk5); break; case 6: OP(mk6); break; default: OP(mk7); break;
 
 #ifndef HM_P_AHEAD_FWD
 #define HM_P_AHEAD_FWD 3         // forward-only kernel: three K-steps ahead (same-box A/B: 1 / 2 / 3 within 1 %)
 #endif
+#ifndef HM_P_ONE_LOOP
+#define HM_P_ONE_LOOP 0
+#endif
 #ifndef HM_P_AHEAD_BWD
-#define HM_P_AHEAD_BWD 1         // forward + backward kernel: one step ahead -- 8 instead of 24 registers across the epilogues
+#define HM_P_AHEAD_BWD 3
 #endif
 
+// MODE 0: forward (sdf only).  MODE 2: forward that also writes the ReLU masks to the launch's scratch block.  MODE 3:
+// backward only -- seed from the sdf and lin7's masks, the eight transposed stages, Jacobian rows.  Forward + backward
+// = a MODE 2 launch followed by a MODE 3 launch on the same stream: one fused kernel held the masks, the xyz-gradient
+// shares and the forward biases next to 128 accumulator registers and spilled 80 ... 400 registers whatever was tried
+// (round 6; 1.35 ms for 131,072 queries against 0.40 + 0.5 for the pair).
 template <int MODE, int TAG>
 __global__ __launch_bounds__(512, 2) void k_decoder_p(const DecodeArgsP a) {
-  constexpr int AH = MODE == 0 ? HM_P_AHEAD_FWD : HM_P_AHEAD_BWD;
+  constexpr bool FWD = MODE != 3, BWD = MODE == 3, MASKS = MODE == 2;
+  constexpr int AH = FWD ? HM_P_AHEAD_FWD : HM_P_AHEAD_BWD;
   __shared__ f16x8 xp[64 * TQP];   // 128 KiB: X[unit][q][8], fp16
   __shared__ float sc[3072];       // 12 KiB scratch: the tile's xyz (forward) / xyz weight columns / lin8 partials + dy / final xyz-gradient sums
   __shared__ float bl[9 * HID];    // 18 KiB: biases of the 8 forward stages (per-instance c0 / c4 included) + lin8's row;
@@ -172,15 +192,19 @@ __global__ __launch_bounds__(512, 2) void k_decoder_p(const DecodeArgsP a) {
     ws.v0 = lane * 16; ws.v1 = lane * 16 + 1024;
   }
   int sq = 0;                      // byte position of the current stage's step 0 in the stream
+  if (BWD) {
+#pragma unroll
+    for (int s = 0; s < 8; ++s) sq += a.dec.pgrp[s] * 8192;
+  }
   ASetP a0, a1, a2, a3;
-  a0.r[0] = wload_p(ws, 0, 0);    a0.r[1] = wload_p(ws, 1, 0);
+  a0.r[0] = wload_p(ws, 0, sq);    a0.r[1] = wload_p(ws, 1, sq);
   a1.r[0] = zero8; a1.r[1] = zero8; a2.r[0] = zero8; a2.r[1] = zero8; a3.r[0] = zero8; a3.r[1] = zero8;
-  if (AH >= 2) { a1.r[0] = wload_p(ws, 0, 2048); a1.r[1] = wload_p(ws, 1, 2048); }
-  if (AH >= 3) { a2.r[0] = wload_p(ws, 0, 4096); a2.r[1] = wload_p(ws, 1, 4096); }
+  if (AH >= 2) { a1.r[0] = wload_p(ws, 0, sq + 2048); a1.r[1] = wload_p(ws, 1, sq + 2048); }
+  if (AH >= 3) { a2.r[0] = wload_p(ws, 0, sq + 4096); a2.r[1] = wload_p(ws, 1, sq + 4096); }
 
   // stage 0 input: rows 0..2 = xyz (unit 0, elements 0..2), every other row of the padded K-steps 0..3 (units 0..7) = 0;
   // queries past the end of the instance read as 0.  The tile's xyz also waits in sc for lin3's splice.
-  if (tid < TQP) {
+  if (FWD && tid < TQP) {
     const f32x4 p = tid < cnt ? pts4[qbase + tid] : zero4;
     f16x8 u0 = zero8;
     u0[0] = (_Float16)p[0]; u0[1] = (_Float16)p[1]; u0[2] = (_Float16)p[2];
@@ -190,25 +214,56 @@ __global__ __launch_bounds__(512, 2) void k_decoder_p(const DecodeArgsP a) {
     sc[0 * TQP + tid] = p[0]; sc[1 * TQP + tid] = p[1]; sc[2 * TQP + tid] = p[2];
   }
 
-  Mask mk0 = {}, mk1 = {}, mk2 = {}, mk3 = {}, mk4 = {}, mk5 = {}, mk6 = {}, mk7 = {};
+  Mask mk = {};                    // masks of the stage's layer: built (forward) or fetched ahead of the K loop (backward)
   f32x16 acc[NRB][NQB];
-  float gx[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};     // d sdf / d xyz through lin0 of queries (lane, lane + 64), this wave's share
-  float y_keep = 0.f;
   // fp16 range guard (see hm_decoder_h.hip), kept on the PACKED fp16 values that go to X: largest stored activation /
   // gradient and smallest gradient; a tile in which one of them reaches fp16's largest finite value (or inf) is poisoned
   f16x8 gmax = zero8, gmin = zero8;
-  const float* cbias0 = a.c0 + (size_t)b * HID;
-  const float* cbias4 = a.c4 + (size_t)b * HID;
   bl[8 * HID + tid] = a.dec.w8[tid];
-  for (int i = tid; i < 8 * HID; i += 512) {
-    const StageDesc& sb = a.dec.st[i >> 9];
-    const float* src = sb.inst_bias == 1 ? cbias0 : (sb.inst_bias == 2 ? cbias4 : sb.bias);
-    bl[i] = src[i & (HID - 1)];
+  if (FWD) {
+    const float* cbias0 = a.c0 + (size_t)b * HID;
+    const float* cbias4 = a.c4 + (size_t)b * HID;
+    for (int i = tid; i < 8 * HID; i += 512) {
+      const StageDesc& sb = a.dec.st[i >> 9];
+      const float* src = sb.inst_bias == 1 ? cbias0 : (sb.inst_bias == 2 ? cbias4 : sb.bias);
+      bl[i] = src[i & (HID - 1)];
+    }
+  }
+  const int mbx = m >> 5;          // lin3's rows m..m+2 (always rows 29..31 of their block: m = 509 - L, L % 32 == 0) carry xyz
+  if (BWD) {
+    reinterpret_cast<f32x4*>(sc + 1024)[tid] = reinterpret_cast<const f32x4*>(a.dec.w0x)[tid];     // lin0's xyz columns, for the last stage
+    // backward seed: G7 = mask7 . (dy w8) with dy = 1 - sdf^2 (tanh'), from the forward launch's sdf and lin7's masks
+    if (tid < TQP) { const float yv = tid < cnt ? a.y[qbase + tid] : 0.f; sc[tid] = 1.f - yv * yv; }
+    const u32x4 mv = a.mscr[((size_t)blockIdx.x * 8 + 7) * 512 + tid];
+    __syncthreads();
+    float dy[NQB];
+#pragma unroll
+    for (int nb = 0; nb < NQB; ++nb) dy[nb] = sc[nb * 32 + qa];
+#pragma unroll
+    for (int r = 0; r < NRB; ++r) {
+      const int mb = w + 8 * r;
+#pragma unroll
+      for (int nb = 0; nb < NQB; ++nb) {
+        const uint32_t word = mv[2 * r + (nb >> 1)];
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+          f16x8 h;
+#pragma unroll
+          for (int gg = 0; gg < 2; ++gg) {
+            const f32x4 wv = *reinterpret_cast<const f32x4*>(bl + 8 * HID + mb * 32 + 8 * (2 * p + gg) + 4 * hi);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) h[4 * gg + j] = (_Float16)(dy[nb] * wv[j]);
+          }
+          u32x4 d = __builtin_bit_cast(u32x4, h);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) d[i] = apply_mask_p(d[i], word, 4 * p + i + 8 * (nb & 1));
+          xp[(2 * (2 * mb + p) + hi) * TQP + nb * 32 + qa] = __builtin_bit_cast(f16x8, d);
+        }
+      }
+    }
   }
 
-  constexpr int n_stage = MODE == 0 ? 8 : NSTAGE;
-  const int mbx = m >> 5;          // lin3's rows m..m+2 (always rows 29..31 of their block: m = 509 - L, L % 32 == 0) carry xyz
-  for (int s = 0; s < n_stage; ++s) {
+  for (int s = FWD ? 0 : 8; s < (FWD ? 8 : NSTAGE); ++s) {
     const StageDesc& sd = a.dec.st[s];
     const int epi = sd.epi;
     const int n_grp = a.dec.pgrp[s];
@@ -226,11 +281,51 @@ __global__ __launch_bounds__(512, 2) void k_decoder_p(const DecodeArgsP a) {
 #endif
     HM_STAMP(5 * s + 0);
 
-    if (MODE == 1 && epi == EPI_BWD0) {
-      // xyz columns of lin0 (512 x 4) through LDS scratch, then this wave's 64 rows (units 8 w .. 8 w + 7) against both query halves
-      reinterpret_cast<f32x4*>(sc)[tid] = reinterpret_cast<const f32x4*>(a.dec.w0x)[tid];
-      __syncthreads();
-      const f32x4* wx = reinterpret_cast<const f32x4*>(sc);
+    if (BWD && (epi == EPI_BWD || epi == EPI_BWD4)) {      // the layer's masks, on their way while the K loop runs
+      const u32x4 mv = a.mscr[((size_t)blockIdx.x * 8 + sd.layer) * 512 + 64 * w + fresh_lane_p()];
+      mk.w[0] = mv[0]; mk.w[1] = mv[1]; mk.w[2] = mv[2]; mk.w[3] = mv[3];
+    }
+
+#pragma unroll
+    for (int r = 0; r < NRB; ++r)
+#pragma unroll
+      for (int nb = 0; nb < NQB; ++nb) acc[r][nb] = zero16p();
+    HM_STAMP(5 * s + 1);
+#ifdef HM_K1P_TRACE
+    long long* gst = (trc && s == 1) ? g_k1p_trace + 640 + 8 * w : nullptr;    // K-loop group stamps of stage 1
+#else
+    long long* gst = nullptr;
+#endif
+    // A wave whose second block is not valid in this stage (lin3's 16 - L/32 blocks, lin0's transpose) runs the 4-MFMA form
+    // of the loop (HM_P_ONE_LOOP = 1: it runs the full loop on the zero weights its stream holds there instead -- one loop
+    // instantiation, for builds in which the second one costs registers: +9 k clocks per such stage at L = 256)
+    if (u[0] && (u[1] || HM_P_ONE_LOOP)) {
+      k_loop_p<true, true, AH>(acc, a0, a1, a2, a3, ws, sq, n_grp, xp, xo, gst);
+    } else if (u[0]) {
+      k_loop_p<true, false, AH>(acc, a0, a1, a2, a3, ws, sq, n_grp, xp, xo);
+      // the second block's accumulators are not read in this stage: tell the register allocator (no instruction), or 64
+      // registers of zeros ride through this loop
+#pragma unroll
+      for (int nb = 0; nb < NQB; ++nb) asm volatile("" : "=v"(acc[1][nb]));
+    } else {   // no valid row block in this stage: keep the ring in step (the next stage's first three steps)
+      const int sn = sq + n_grp * 8192;
+      a0.r[0] = wload_p(ws, 0, sn);        a0.r[1] = wload_p(ws, 1, sn);
+      if (AH >= 2) { a1.r[0] = wload_p(ws, 0, sn + 2048); a1.r[1] = wload_p(ws, 1, sn + 2048); }
+      if (AH >= 3) { a2.r[0] = wload_p(ws, 0, sn + 4096); a2.r[1] = wload_p(ws, 1, sn + 4096); }
+    }
+    sq += n_grp * 8192;
+    // the sets beyond the first AH are refilled by the next stage's first steps before anyone reads them: end
+    // their live ranges here (no instruction)
+    asm volatile("" : "=v"(a3.r[0]), "=v"(a3.r[1]));
+    if (AH < 3) asm volatile("" : "=v"(a2.r[0]), "=v"(a2.r[1]));
+    if (AH < 2) asm volatile("" : "=v"(a1.r[0]), "=v"(a1.r[1]));
+    if (BWD && epi == EPI_BWD0) {
+      const int lane = fresh_lane_p();
+      // d sdf / d xyz through lin0: the xyz columns of lin0 (staged in sc by the prologue) against X = the gradient at lin0's
+      // output, which this stage does not overwrite -- this wave's 64 rows (units 8 w .. 8 w + 7), both query halves.  AFTER the
+      // K loop: the wave that finishes first does it in the shadow of its SIMD partner's MFMAs
+      const f32x4* wx = reinterpret_cast<const f32x4*>(sc + 1024);
+      float gx[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};     // d sdf / d xyz through lin0 of queries (lane, lane + 64), this wave's share
 #pragma unroll 2
       for (int g = 0; g < 8; ++g) {
         float xa[8], xb[8];
@@ -244,58 +339,17 @@ __global__ __launch_bounds__(512, 2) void k_decoder_p(const DecodeArgsP a) {
           gx[1][0] = fmaf(xb[j], wv[0], gx[1][0]); gx[1][1] = fmaf(xb[j], wv[1], gx[1][1]); gx[1][2] = fmaf(xb[j], wv[2], gx[1][2]);
         }
       }
-    }
-
+      // this wave's share waits in bl[512 ..) (the biases are not needed any more) for the sum at the end of the tile
 #pragma unroll
-    for (int r = 0; r < NRB; ++r)
-#pragma unroll
-      for (int nb = 0; nb < NQB; ++nb) acc[r][nb] = zero16p();
-    if (MODE == 1 && epi == EPI_BWD0) {
-      // d sdf/d z so far (lin4's transpose) was parked in this tile's J rows (true units): seed the accumulators
-      const float rs = 1.f / us;
-#pragma unroll
-      for (int r = 0; r < NRB; ++r) {
-        if (!u[r]) continue;
-        const int jz = (mbr[r] - mb_zx) * 32;
-#pragma unroll
-        for (int nb = 0; nb < NQB; ++nb) {
-          const int q = nb * 32 + qa;
-          if (q < cnt) {
-            const float* row = a.J + (qbase + q) * (size_t)a.ldJ;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-              const f32x4 v = *reinterpret_cast<const f32x4*>(row + jz + 8 * g + 4 * hi);
-#pragma unroll
-              for (int j = 0; j < 4; ++j) acc[r][nb][4 * g + j] = v[j] * rs;
-            }
-          }
-        }
+      for (int c = 0; c < 3; ++c) {
+        bl[512 + (w * 3 + c) * TQP + lane] = gx[0][c];
+        bl[512 + (w * 3 + c) * TQP + 64 + lane] = gx[1][c];
       }
     }
-
-    HM_STAMP(5 * s + 1);
-#ifdef HM_K1P_TRACE
-    long long* gst = (trc && s == 1) ? g_k1p_trace + 640 + 8 * w : nullptr;    // K-loop group stamps of stage 1
-    if (u[0] && u[1]) k_loop_p<true, true, AH>(acc, a0, a1, a2, a3, ws, sq, n_grp, xp, xo, gst);
-    else
-#endif
-    if (u[0] && u[1]) k_loop_p<true, true, AH>(acc, a0, a1, a2, a3, ws, sq, n_grp, xp, xo);
-    else if (u[0]) k_loop_p<true, false, AH>(acc, a0, a1, a2, a3, ws, sq, n_grp, xp, xo);
-    else {   // no valid row block in this stage: keep the ring in step (the next stage's first three steps)
-      const int sn = sq + n_grp * 8192;
-      a0.r[0] = wload_p(ws, 0, sn);        a0.r[1] = wload_p(ws, 1, sn);
-      if (AH >= 2) { a1.r[0] = wload_p(ws, 0, sn + 2048); a1.r[1] = wload_p(ws, 1, sn + 2048); }
-      if (AH >= 3) { a2.r[0] = wload_p(ws, 0, sn + 4096); a2.r[1] = wload_p(ws, 1, sn + 4096); }
-    }
-    sq += n_grp * 8192;
-    // the sets beyond the first AH are refilled by the next stage's first steps before anyone reads them: end
-    // their live ranges here (no instruction)
-    asm volatile("" : "=v"(a3.r[0]), "=v"(a3.r[1]));
-    if (AH < 3) asm volatile("" : "=v"(a2.r[0]), "=v"(a2.r[1]));
-    if (AH < 2) asm volatile("" : "=v"(a1.r[0]), "=v"(a1.r[1]));
     HM_STAMP(5 * s + 2);
 
     // ---- conversion on registers (no access to X): unit p of block (r, nb) = the 16 bytes X[2 (2 mb + p) + hi][nb * 32 + qa] ----
+    const int lane = fresh_lane_p(), tid = 64 * w + lane, qa = lane & 31, hi = lane >> 5;
     bool st_x[NRB] = {false, false};
 #ifdef ABL_NOEPI       // timing ablation (wrong results): K loops and barriers only
 #pragma unroll
@@ -304,10 +358,10 @@ __global__ __launch_bounds__(512, 2) void k_decoder_p(const DecodeArgsP a) {
       for (int nb = 0; nb < NQB; ++nb) asm volatile("" :: "v"(acc[r][nb]));
     if (false) {
 #else
-    if (MODE == 0 || epi <= EPI_FWD7) {
+    if (FWD) {
 #endif
       const float* bias = bl + s * HID;
-      Mask mk = {};
+      mk = Mask{};
       const f32x8 us8 = {us, us, us, us, us, us, us, us};
 #pragma unroll
       for (int r = 0; r < NRB; ++r) {
@@ -332,7 +386,7 @@ __global__ __launch_bounds__(512, 2) void k_decoder_p(const DecodeArgsP a) {
 #pragma unroll
               for (int e = 0; e < 8; ++e) { av[e] = acc[r][nb][8 * p + e]; bb[e] = bv[2 * p + (e >> 2)][e & 3]; }
               f16x8 h = __builtin_convertvector(__builtin_elementwise_fma(av, us8, bb), f16x8);
-              if (MODE == 1) {
+              if (MASKS) {
                 const u32x4 d = __builtin_bit_cast(u32x4, h);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) chain = (chain >> 1) | (d[i] & 0x80008000u);
@@ -358,14 +412,11 @@ __global__ __launch_bounds__(512, 2) void k_decoder_p(const DecodeArgsP a) {
           }
         }
       }
-#define HM_SET(M) M = mk
-      if (MODE == 1) switch (sd.layer) { HM_MASK_CASES(HM_SET) }
-#undef HM_SET
-    } else if (MODE == 1 && (epi == EPI_BWD || epi == EPI_BWD4)) {
-      Mask mk;
-#define HM_GET(M) mk = M
-      switch (sd.layer) { HM_MASK_CASES(HM_GET) }
-#undef HM_GET
+      if (MASKS) {
+        const u32x4 mv = {mk.w[0], mk.w[1], mk.w[2], mk.w[3]};
+        a.mscr[((size_t)blockIdx.x * 8 + sd.layer) * 512 + tid] = mv;
+      }
+    } else if (epi == EPI_BWD || epi == EPI_BWD4) {
 #pragma unroll
       for (int r = 0; r < NRB; ++r) {
         if (!u[r]) continue;
@@ -419,7 +470,7 @@ __global__ __launch_bounds__(512, 2) void k_decoder_p(const DecodeArgsP a) {
           HM_FENCE();
         }
       }
-    } else if (MODE == 1) {  // EPI_BWD0
+    } else {  // EPI_BWD0
 #pragma unroll
       for (int r = 0; r < NRB; ++r) {
         if (!u[r]) continue;
@@ -431,9 +482,10 @@ __global__ __launch_bounds__(512, 2) void k_decoder_p(const DecodeArgsP a) {
             float* row = a.J + (qbase + q) * (size_t)a.ldJ;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-              f32x4 v;
+              // d sdf / d z = lin4's share (parked in this row by the same thread, stage 11) + lin0's
+              f32x4 v = *reinterpret_cast<const f32x4*>(row + jz + 8 * g + 4 * hi);
 #pragma unroll
-              for (int j = 0; j < 4; ++j) v[j] = acc[r][nb][4 * g + j] * us;
+              for (int j = 0; j < 4; ++j) v[j] = fmaf(acc[r][nb][4 * g + j], us, v[j]);
               *reinterpret_cast<f32x4*>(row + jz + 8 * g + 4 * hi) = v;
             }
           }
@@ -464,7 +516,7 @@ __global__ __launch_bounds__(512, 2) void k_decoder_p(const DecodeArgsP a) {
     }
 #endif
 
-    if (epi == EPI_FWD7) {
+    if (FWD && epi == EPI_FWD7) {
       __syncthreads();
       float pa = 0.f, pb = 0.f;
 #pragma unroll 2
@@ -490,61 +542,29 @@ __global__ __launch_bounds__(512, 2) void k_decoder_p(const DecodeArgsP a) {
         for (int i = 0; i < NWP; ++i) a8 += sc[i * TQP + tid];
         a8 += a.dec.b8;
         const float yv = tanhf(a8);
-        y_keep = yv;
         if (tid < cnt) a.y[qbase + tid] = yv;
-        sc[NWP * TQP + tid] = 1.f - yv * yv;
       }
-      if (MODE == 0) return;
-      __syncthreads();
-      // backward seed: G7 = mask7 . (dy w8), straight into X (every wave's lin8 reads are behind the barriers above)
-      float dy[NQB];
-#pragma unroll
-      for (int nb = 0; nb < NQB; ++nb) dy[nb] = sc[NWP * TQP + nb * 32 + qa];
-#pragma unroll
-      for (int r = 0; r < NRB; ++r) {
-        const int mb = mbr[r];
-#pragma unroll
-        for (int nb = 0; nb < NQB; ++nb) {
-          const uint32_t word = mk7.w[2 * r + (nb >> 1)];
-#pragma unroll
-          for (int p = 0; p < 2; ++p) {
-            f16x8 h;
-#pragma unroll
-            for (int gg = 0; gg < 2; ++gg) {
-              const f32x4 wv = *reinterpret_cast<const f32x4*>(bl + 8 * HID + mb * 32 + 8 * (2 * p + gg) + 4 * hi);
-#pragma unroll
-              for (int j = 0; j < 4; ++j) h[4 * gg + j] = (_Float16)(dy[nb] * wv[j]);
-            }
-            u32x4 d = __builtin_bit_cast(u32x4, h);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) d[i] = apply_mask_p(d[i], word, 4 * p + i + 8 * (nb & 1));
-            xp[(2 * (2 * mb + p) + hi) * TQP + nb * 32 + qa] = __builtin_bit_cast(f16x8, d);
-          }
-        }
-      }
+      return;
     }
   }
 
-  if (MODE == 0) return;
-  if (__any(guard_tripped_p(gmax, gmin))) { gx[0][0] = __builtin_nanf(""); gx[1][0] = gx[0][0]; }
+  if (FWD) return;
+  const bool poisoned = __any(guard_tripped_p(gmax, gmin));
   __syncthreads();
-#pragma unroll
-  for (int c = 0; c < 3; ++c) {
-    sc[(w * 3 + c) * TQP + lane] = gx[0][c];
-    sc[(w * 3 + c) * TQP + 64 + lane] = gx[1][c];
-  }
-  __syncthreads();
-  if (tid < cnt) {
+  const int tid_e = 64 * w + fresh_lane_p();
+  if (tid_e < cnt) {
+    const int tid = tid_e;
     float g0 = bl[0 * TQP + tid], g1 = bl[1 * TQP + tid], g2 = bl[2 * TQP + tid];     // through lin4 (matrix pipe)
 #pragma unroll
-    for (int i = 0; i < NWP; ++i) {
-      g0 += sc[(i * 3 + 0) * TQP + tid];
-      g1 += sc[(i * 3 + 1) * TQP + tid];
-      g2 += sc[(i * 3 + 2) * TQP + tid];
+    for (int i = 0; i < NWP; ++i) {                                                    // through lin0 (the eight waves' shares)
+      g0 += bl[512 + (i * 3 + 0) * TQP + tid];
+      g1 += bl[512 + (i * 3 + 1) * TQP + tid];
+      g2 += bl[512 + (i * 3 + 2) * TQP + tid];
     }
+    if (poisoned) g0 = __builtin_nanf("");
     const f32x4 p = pts4[qbase + tid];
     float* row = a.J + (qbase + tid) * (size_t)a.ldJ + L;
-    row[7] = y_keep;
+    row[7] = a.y[qbase + tid];       // the residual column = sdf (written by this thread after lin8)
     row[0] = g0; row[1] = g1; row[2] = g2;
     if (a.pose_dim != 0) {
       row[3] = g2 * p[1] - g1 * p[2];
@@ -579,10 +599,30 @@ int launch_decoder_p(const hm_decoder_s* dec, int B, const float* d_pts, const i
   a.y = d_y; a.J = d_J; a.n_stride = n_stride; a.B = B; a.ldJ = ldJ; a.pose_dim = pose_dim;
   const int grid = B * ((n_stride + TQP - 1) / TQP);
   if (grid == 0) return 0;
-  if (mode == 0) hipLaunchKernelGGL((k_decoder_p<0, 0>), dim3(grid), dim3(512), 0, stream, a);
-  else if (tag == 0) hipLaunchKernelGGL((k_decoder_p<1, 0>), dim3(grid), dim3(512), 0, stream, a);
-  else hipLaunchKernelGGL((k_decoder_p<1, 1>), dim3(grid), dim3(512), 0, stream, a);
-  HM_CHECK_HIP(hipGetLastError());
+  a.mscr = nullptr;
+  if (mode == 0) {
+    hipLaunchKernelGGL((k_decoder_p<0, 0>), dim3(grid), dim3(512), 0, stream, a);
+    HM_CHECK_HIP(hipGetLastError());
+    return 0;
+  }
+  // forward + backward = two launches: forward with the ReLU masks written to a scratch block (64 KiB per workgroup), then
+  // the backward-only kernel.  The block is STREAM-ORDERED (allocated and released on the launch's stream): concurrent
+  // launches on one decoder handle -- instance groups, several workspaces, host threads -- never share it, and nothing
+  // outlives the pair
+  void* scr = nullptr;
+  HM_CHECK_HIP(hipMallocAsync(&scr, (size_t)grid * 8 * 512 * sizeof(u32x4), stream));
+  a.mscr = static_cast<u32x4*>(scr);
+  if (tag == 0) {
+    hipLaunchKernelGGL((k_decoder_p<2, 0>), dim3(grid), dim3(512), 0, stream, a);
+    hipLaunchKernelGGL((k_decoder_p<3, 0>), dim3(grid), dim3(512), 0, stream, a);
+  } else {
+    hipLaunchKernelGGL((k_decoder_p<2, 1>), dim3(grid), dim3(512), 0, stream, a);
+    hipLaunchKernelGGL((k_decoder_p<3, 1>), dim3(grid), dim3(512), 0, stream, a);
+  }
+  const hipError_t le = hipGetLastError();
+  const hipError_t fe = hipFreeAsync(scr, stream);
+  HM_CHECK_HIP(le);
+  HM_CHECK_HIP(fe);
   return 0;
 }
 
