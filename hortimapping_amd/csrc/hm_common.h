@@ -103,7 +103,6 @@ struct hm_decoder_s {
   int L;
   int generic;         // 1: built by hm_decoder_create_arch: `any` is valid, `dev` is not; precisions 0 (exact fp32) and 1 (f16x3)
   hm::AnyDev any;
-  void* d_any_slab;    // per-workgroup scratch of the any-architecture kernel (LayerNorm saves + d sdf / d z block)
 };
 
 #define HM_CHECK_HIP(expr)                                                        \

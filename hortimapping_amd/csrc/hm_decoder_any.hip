@@ -744,12 +744,24 @@ int launch_decoder_any(const hm_decoder_s* dec, int B, const float* d_pts, const
   AnyArgs a;
   a.dec = dec->any;
   a.pts = d_pts; a.n_q = d_nq; a.active = d_active; a.zc = d_zc; a.y = d_y; a.J = d_J;
-  a.ln_slab = static_cast<float*>(dec->d_any_slab);
-  a.gi_slab = a.ln_slab + (size_t)ANY_GRID * dec->any.n_ln * SLAB;
   a.n_stride = n_stride; a.B = B; a.ldJ = ldJ; a.pose_dim = pose_dim;
   a.n_tiles = B * (n_stride / TQ);
   if (a.n_tiles == 0) return 0;
   const int grid = a.n_tiles < ANY_GRID ? a.n_tiles : ANY_GRID;
+  // The per-workgroup scratch of the backward pass (LayerNorm saves + the d sdf / d z block) belongs to the LAUNCH: it is
+  // allocated and released on the launch's stream.  (Up to round 5 it was one block per decoder handle, indexed by
+  // blockIdx.x only: the two instance groups of hm_optimize_batch, two workspaces or two host threads on one handle
+  // then read-modify-wrote each other's slots.)  The forward-only kernels do not touch it.
+  if (dec->precision != 0 && dec->precision != 1) {
+    hm_set_error("any-architecture decoder: precision %d not available (0 = exact fp32, 1 = f16x3)", dec->precision);
+    return -1;
+  }
+  void* slab = nullptr;
+  if (mode != 0) {
+    HM_CHECK_HIP(hipMallocAsync(&slab, (size_t)grid * ((size_t)dec->any.n_ln * SLAB + MAX_L * 64) * sizeof(float), stream));
+  }
+  a.ln_slab = static_cast<float*>(slab);
+  a.gi_slab = a.ln_slab + (size_t)grid * dec->any.n_ln * SLAB;
   const bool ln = dec->any.n_ln > 0;      // tables without LayerNorm run kernels compiled without its code paths
 #define HM_ANY_LAUNCH(K, M)                                                                     \
   do {                                                                                          \
@@ -758,17 +770,15 @@ int launch_decoder_any(const hm_decoder_s* dec, int B, const float* d_pts, const
   } while (0)
   if (dec->precision == 1) {
     if (mode == 0) HM_ANY_LAUNCH(k_decoder_any_h, 0); else HM_ANY_LAUNCH(k_decoder_any_h, 1);
-  } else if (dec->precision != 0) {
-    hm_set_error("any-architecture decoder: precision %d not available (0 = exact fp32, 1 = f16x3)", dec->precision);
-    return -1;
   } else {
     if (mode == 0) HM_ANY_LAUNCH(k_decoder_any, 0); else HM_ANY_LAUNCH(k_decoder_any, 1);
   }
 #undef HM_ANY_LAUNCH
-  HM_CHECK_HIP(hipGetLastError());
+  const hipError_t le = hipGetLastError();
+  const hipError_t fe = slab != nullptr ? hipFreeAsync(slab, stream) : hipSuccess;
+  HM_CHECK_HIP(le);
+  HM_CHECK_HIP(fe);
   return 0;
 }
-
-size_t any_slab_bytes(int n_ln) { return (size_t)ANY_GRID * ((size_t)n_ln * SLAB + MAX_L * 64) * sizeof(float); }
 
 }  // namespace hm

@@ -151,7 +151,6 @@ int launch_latent_copy_any(const hm_decoder_s* dec, const float* d_latent, int l
 int launch_decoder_any(const hm_decoder_s* dec, int B, const float* d_pts, const int* d_nq, const int* d_active,
                        int n_stride, const float* d_zc, float* d_y, float* d_J, int ldJ, int pose_dim, int mode,
                        hipStream_t stream);
-size_t any_slab_bytes(int n_ln);
 
 int launch_normal_eq(const RowSegment* segs, int n_seg, int L, int B, const int* d_active, float* d_Hext,
                      hipStream_t stream, int split_f16 = 0);    // split_f16: K4h (fp16 MFMA on split operands) for the f16x3 arithmetics

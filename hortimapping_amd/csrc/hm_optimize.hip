@@ -264,8 +264,11 @@ RenderCfg make_render_cfg(const hm_workspace_s* ws, const hm_opt_cfg* cfg) {
   rc.log_occ = cfg->log_sdf_occ; rc.occlusion_on = cfg->occlusion_on; rc.scale_on = cfg->scale_on;
   rc.occ_th = cfg->occ_cutoff; rc.occlusion_th = cfg->occlusion_th; rc.min_grad = cfg->min_grad_thre;
   rc.min_valid = cfg->min_valid_sample;
-  // screening applies to the f16x3 render chain under LINEAR occupancy only (logistic occupancy never saturates exactly)
-  rc.screen = ((ws->dec->precision == 1 || ws->dec->precision == 2) && !ws->split_render && !cfg->log_sdf_occ) ? ws->screen_mode : 0;
+  // screening applies to the f16x3 render chain under LINEAR occupancy only (logistic occupancy never saturates exactly),
+  // and its dead-sample rule needs min_grad_thre >= 0 (a sample behind a certainly-inside one has de_do == 0 or 0/0, which
+  // must FAIL `de_do > min_grad_thre` as it does in the reference, loss.py:66; a negative threshold would keep it)
+  rc.screen = ((ws->dec->precision == 1 || ws->dec->precision == 2) && !ws->split_render && !cfg->log_sdf_occ &&
+               cfg->min_grad_thre >= 0.f) ? ws->screen_mode : 0;
   rc.screen_eps = ws->screen_eps;
   rc.flat_jac = ((ws->dec->precision == 1 || ws->dec->precision == 2) && !ws->split_render) ? 1 : 0;
   return rc;
@@ -792,7 +795,7 @@ int group_count(const hm_workspace_s* ws, int B, const hm_debug* dbg) {
 
 }  // namespace
 
-// A/B + tests: 0 = the f16x3 arithmetics keep the fp32-input normal-equation kernel (rounds 1-4), 1 = K4h (default)
+// A/B + tests: 0 = the f16x3 arithmetics keep the fp32-input normal-equation kernel (the default), 1 = K4h (opt-in)
 extern "C" int hm_workspace_set_k4_split(hm_workspace_s* w, int on) {
   if (w == nullptr) { hm_set_error("null workspace"); return -1; }
   w->k4_split = (on < 0 || on > 2) ? 0 : on;

@@ -332,7 +332,6 @@ extern "C" int hm_decoder_create_arch(const hm_decoder_arch* arch, const float* 
   e = hipMemcpy(d->d_blob, blob.host.data(), blob.host.size() * sizeof(float), hipMemcpyHostToDevice);
   if (e == hipSuccess)
     e = hipMemcpy(static_cast<char*>(d->d_blob) + fbytes, hblob.data(), hblob.size() * sizeof(uint16_t), hipMemcpyHostToDevice);
-  if (e == hipSuccess) e = hipMalloc(&d->d_any_slab, any_slab_bytes(n_ln));
   if (e != hipSuccess) {
     hm_set_error("device allocation / copy failed: %s", hipGetErrorString(e));
     (void)hipFree(d->d_blob); delete d; return -2;
@@ -359,7 +358,6 @@ extern "C" int hm_decoder_create_arch(const hm_decoder_arch* arch, const float* 
 extern "C" int hm_decoder_destroy(hm_decoder_s* d) {
   if (d == nullptr) return 0;
   (void)hipFree(d->d_blob);
-  (void)hipFree(d->d_any_slab);
   delete d;
   return 0;
 }

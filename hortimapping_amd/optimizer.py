@@ -400,7 +400,28 @@ def optimize_batch(dec: DecoderWeights, opt: dict, instances: Sequence[Instance]
             pb = PackedBatch(instances, L, n_frame, device, F_cap=l.max_frames, R_cap=l.max_rays)
     if cache is not None:
         cache["ws"] = workspace
-    run_packed(workspace, cfg, pb, 1 if shape_only else 0, debug)
+    # Linear-occupancy screening (include/hortimapping_amd.h): exact as long as the one-pass fp16 sdf stays within the
+    # margin of the f16x3 value -- measured on four decoders, not a property of every decoder a user may train.  So the
+    # FIRST screened call on a decoder handle runs in verify mode (the exact forward over every sample rides along and
+    # contradicted decisions are counted): no violation -> the handle is trusted from then on; any violation -> this call
+    # is repeated from its initial state without screening and the handle never screens again.
+    screened = (not shape_only and not cfg.log_sdf_occ and cfg.min_grad_thre >= 0 and not dec.generic
+                and dec.precision in ("f16x3", "f16x3f_f16b"))
+    state = getattr(dec, "_screening", None) if screened else None
+    if screened and state is None:
+        init = (pb.latent.clone(), pb.T_ow.clone())
+        workspace.set_screening(2)
+        run_packed(workspace, cfg, pb, 0, debug)
+        bad = workspace.screening_stats(reset=True)["violations"]
+        dec._screening = "off" if bad else "trusted"
+        workspace.set_screening(0 if bad else 1)
+        if bad:
+            pb.latent.copy_(init[0]); pb.T_ow.copy_(init[1])
+            run_packed(workspace, cfg, pb, 0, debug)
+    else:
+        if screened:
+            workspace.set_screening(1 if state == "trusted" else 0)
+        run_packed(workspace, cfg, pb, 1 if shape_only else 0, debug)
     # one D2H transfer for the whole batch (the copy synchronises with the stream the optimisation was enqueued on)
     rec = torch.cat([pb.latent, pb.T_ow, pb.iter_count.to(torch.float32)[:, None],
                      pb.status.to(torch.float32)[:, None]], dim=1).cpu()
