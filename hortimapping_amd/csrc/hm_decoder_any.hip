@@ -393,9 +393,8 @@ __device__ __forceinline__ void run_gemm_h(f32x16 (&acc)[2][2], const void* wp, 
                                            const f16x8* xl, int lane) {
   acc[0][0] = zero16(); acc[0][1] = zero16(); acc[1][0] = zero16(); acc[1][1] = zero16();
   const bool u0 = w < n_rb, u1 = w + NWAVE < n_rb;
-  const f16x8* wp8 = reinterpret_cast<const f16x8*>(wp);
-  const f16x8* wp0 = wp8 + (size_t)w * n_k16 * 128 + lane;
-  const f16x8* wp1 = wp8 + (size_t)(w + NWAVE) * n_k16 * 128 + lane;
+  const WSrc wp0 = make_wsrc(wp, w * n_k16 * 128 + lane);
+  const WSrc wp1 = make_wsrc(wp, (w + NWAVE) * n_k16 * 128 + lane);
   if (u0 && u1) gemm_loop_h<true, true>(acc, wp0, wp1, n_k16, xh, xl, lane);
   else if (u0) gemm_loop_h<true, false>(acc, wp0, wp1, n_k16, xh, xl, lane);
 }

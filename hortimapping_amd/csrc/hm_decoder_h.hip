@@ -74,10 +74,10 @@ struct BSet1 { f16x8 h0, h1; };
 
 template <bool U0, bool U1>
 __device__ __forceinline__ void step_h1(f32x16 (&acc)[2][2], const ASet1& a, const BSet1& b, ASet1& an, BSet1& bn,
-                                        const f16x8* __restrict__ wp0, const f16x8* __restrict__ wp1, int ka,
+                                        const WSrc wp0, const WSrc wp1, int ka,
                                         const f16x8* xh, int kb, int xo) {
-  const f16x8* w0 = wp0 + ka * 128;
-  const f16x8* w1 = wp1 + ka * 128;
+  const WSrc w0 = wp0 + ka * 128;
+  const WSrc w1 = wp1 + ka * 128;
   const f16x8* ph = xh + kb * 2 * TQ + xo;
   HM_FENCE();
   if (U0) { HM_MFMA(a.h0, b.h0, acc[0][0]); HM_MFMA(a.h0, b.h1, acc[0][1]); }
@@ -91,8 +91,8 @@ __device__ __forceinline__ void step_h1(f32x16 (&acc)[2][2], const ASet1& a, con
 }
 
 template <bool U0, bool U1>
-__device__ __forceinline__ void gemm_loop_h1(f32x16 (&acc)[2][2], const f16x8* __restrict__ wp0,
-                                             const f16x8* __restrict__ wp1, int n_k16, const f16x8* xh, int lane) {
+__device__ __forceinline__ void gemm_loop_h1(f32x16 (&acc)[2][2], const WSrc wp0,
+                                             const WSrc wp1, int n_k16, const f16x8* xh, int lane) {
   const int xo = (lane >> 5) * TQ + (lane & 31);
   const int last = n_k16 - 1;
   ASet1 a0 = {}, a1 = {}, a2 = {}, a3 = {};
@@ -343,9 +343,8 @@ __global__ __launch_bounds__(512, 2) void k_decoder_h(const DecodeArgsH a) {
     }
 
     {
-      const f16x8* wp = reinterpret_cast<const f16x8*>(sh.wp);
-      const f16x8* wp0 = wp + (size_t)(mb0 - sd.mb_lo) * sh.mb_stride + lane;
-      const f16x8* wp1 = wp + (size_t)(mb1 - sd.mb_lo) * sh.mb_stride + lane;
+      const WSrc wp0 = make_wsrc(sh.wp, (mb0 - sd.mb_lo) * sh.mb_stride + lane);
+      const WSrc wp1 = make_wsrc(sh.wp, (mb1 - sd.mb_lo) * sh.mb_stride + lane);
       if (BW1 && s >= 8) {
         if (u0 && u1) gemm_loop_h1<true, true>(acc, wp0, wp1, sh.n_k16, xh, lane);
         else if (u0) gemm_loop_h1<true, false>(acc, wp0, wp1, sh.n_k16, xh, lane);

@@ -79,11 +79,30 @@ __device__ __forceinline__ float mask_keep(float x, uint32_t bits, int pos) {
 // activations (B, from LDS) one step ahead into a ring of two; the loop is unrolled by six so every set has a fixed
 // name (no register rotation => hipcc emits counted waits instead of draining vmcnt/lgkmcnt each step), and
 // sched_barriers pin each prefetch between the MFMAs it overlaps (hipcc otherwise sinks loads to their first use).
+// The weight operand's source: the stage's packed weights as a BUFFER (descriptor in SGPRs), this lane's fixed byte offset
+// in it (row block + lane, one VGPR) and a wave-uniform byte offset (K step; scalar).  It indexes like the pointer it
+// replaces -- wp + k, wp[k], k in 16-byte units -- but every fetch is a buffer_load_dwordx4 whose only per-lane operand
+// never changes: round-6 measurement (scripts/microbench/issue_cost.hip, profiles/r06_issue_cost.txt): with weight fetches
+// on 64-bit per-lane addresses (global_load_dwordx4 v, v[a:b], off: what pointer indexing compiled to) a SIMD's two
+// waves take 576-611 clocks per 16 MFMAs + 2 fetches + 4 LDS reads each, with this form 544 (512 = the matrix pipe alone).
+struct WSrc {
+  __amdgpu_buffer_rsrc_t rs;
+  int voff, soff;
+  __device__ __forceinline__ WSrc operator+(int k) const { return WSrc{rs, voff, soff + k * 16}; }
+  __device__ __forceinline__ f16x8 operator[](int k) const {
+    return __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff + k * 16, 0));
+  }
+};
+// base: wave-uniform start of the stage's weights; lane_unit: this lane's position in it, in 16-byte units
+__device__ __forceinline__ WSrc make_wsrc(const void* base, int lane_unit) {
+  return WSrc{__builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7ffffff0, 0x00020000), lane_unit * 16, 0};
+}
+
 struct ASet { f16x8 h0, l0, h1, l1; };
 struct BSet { f16x8 h0, h1, l0, l1; };
 
 template <bool U0, bool U1>
-__device__ __forceinline__ void load_a(ASet& a, const f16x8* __restrict__ wp0, const f16x8* __restrict__ wp1, int k) {
+__device__ __forceinline__ void load_a(ASet& a, const WSrc wp0, const WSrc wp1, int k) {
   if (U0) { a.h0 = wp0[k * 128]; a.l0 = wp0[k * 128 + 64]; }
   if (U1) { a.h1 = wp1[k * 128]; a.l1 = wp1[k * 128 + 64]; }
 }
@@ -107,11 +126,11 @@ __device__ __forceinline__ void load_b(BSet& b, const f16x8* xh, const f16x8* xl
 // instead of in front of them.  Activation reads (needed next step) go first, weight fetches (needed two steps on) last.
 template <bool U0, bool U1>
 __device__ __forceinline__ void step_h(f32x16 (&acc)[2][2], const ASet& a, const BSet& b, ASet& an, BSet& bn,
-                                       const f16x8* __restrict__ wp0, const f16x8* __restrict__ wp1, int ka,
+                                       const WSrc wp0, const WSrc wp1, int ka,
                                        const f16x8* xh, const f16x8* xl, int kb, int xo) {
   const _Float16 cs = (_Float16)LO_UNSCALE;
-  const f16x8* w0 = wp0 + ka * 128;
-  const f16x8* w1 = wp1 + ka * 128;
+  const WSrc w0 = wp0 + ka * 128;
+  const WSrc w1 = wp1 + ka * 128;
   const f16x8* ph = xh + kb * 2 * TQ + xo;
   const f16x8* pl = xl + kb * 2 * TQ + xo;
   if (U0 && U1) {
@@ -163,8 +182,8 @@ __device__ __forceinline__ void step_h(f32x16 (&acc)[2][2], const ASet& a, const
 // (or two, `alt_shift` = 1) each, so that neither runs ahead of the other for a whole K loop (`alt_half` = 0 for the
 // older half of the workgroup, 1 for the younger).
 template <bool U0, bool U1, bool ALT = false>
-__device__ __forceinline__ void gemm_loop_h(f32x16 (&acc)[2][2], const f16x8* __restrict__ wp0,
-                                            const f16x8* __restrict__ wp1, int n_k16, const f16x8* xh,
+__device__ __forceinline__ void gemm_loop_h(f32x16 (&acc)[2][2], const WSrc wp0,
+                                            const WSrc wp1, int n_k16, const f16x8* xh,
                                             const f16x8* xl, int lane, int alt_half = 0, int alt_shift = 0) {
   const int xo = (lane >> 5) * TQ + (lane & 31);
   const int last = n_k16 - 1;
