@@ -180,11 +180,19 @@ def shipped_config_bench(name, precision, steps=3, warmup=1, n_groups=0):
         groups.append(dict(yaml=y, opt=opt, hcfg=hcfg, pb=pb, ws=ws, dec=dec, known=known, shape=shape,
                            init=(pb.latent.clone(), pb.T_ow.clone()), E=L + (7 if opt["scale_on"] else 6)))
 
+    def one(g):
+        g["pb"].latent.copy_(g["init"][0])
+        g["pb"].T_ow.copy_(g["init"][1])
+        HO.run_packed(g["ws"], g["hcfg"], g["pb"], 0)
+
     def step():
-        for g in groups:
-            g["pb"].latent.copy_(g["init"][0])
-            g["pb"].T_ow.copy_(g["init"][1])
-            HO.run_packed(g["ws"], g["hcfg"], g["pb"], 0)
+        # several (decoder, YAML) groups = configs[4]: at the same time, as optimize_grouped runs them (one host thread +
+        # leased group streams per call; HM_SERIAL_GROUPS=1: back to back, the round-5 schedule, for the A/B)
+        if len(groups) > 1 and os.environ.get("HM_SERIAL_GROUPS", "0") != "1":
+            HO.run_concurrent([(lambda g=g: one(g)) for g in groups])
+        else:
+            for g in groups:
+                one(g)
 
     for _ in range(warmup):
         step()

@@ -447,25 +447,49 @@ namespace {
 // hardware queues, and every additional workspace with streams of its own -- the drop-in Optimizer's cache, its exact-f32
 // retry workspace, a second decoder, the nested runs of bench.py -- shifted the mapping until the two groups of a call
 // shared a queue and ran back to back (round 5: `c2_joint2048` 92 instances/s as a nested run of the bench process against
-// 101-103 in a fresh process, same box).  Sharing the pool is safe: a call forks from and joins back into the caller's stream by
-// events, and two calls in flight at once (two workspaces, two host threads) merely take turns on a group stream.
+// 101-103 in a fresh process, same box).  A call LEASES its group streams for its duration (round 6): calls that are in
+// flight at the same time -- two workspaces driven from two host threads, e.g. the pepper and the berry group of BASELINE
+// configs[4] (optimizer.py: run_packed_concurrent) -- get DISJOINT streams, so neither waits behind the other's launches;
+// a call that finds fewer idle streams than it wants groups runs with the groups it can get (results never depend on the
+// grouping), down to one group on the caller's own stream.  A lease ends when the call has recorded its join events: the
+// next holder's work is ordered behind whatever is still in flight on the stream, which is all the safety needed.
 constexpr int HM_MAX_DEV = 16;
 std::mutex g_pool_mu;
 hipStream_t g_pool[HM_MAX_DEV][hm_workspace_s::G_MAX];
+bool g_pool_busy[HM_MAX_DEV][hm_workspace_s::G_MAX];
 int g_pool_n[HM_MAX_DEV];
 
-int pool_stream(int g, hipStream_t* out) {
+struct PoolLease {
+  int dev = -1, n = 0;
+  int idx[hm_workspace_s::G_MAX];
+  hipStream_t st[hm_workspace_s::G_MAX];
+  ~PoolLease() {
+    if (n == 0) return;
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    for (int i = 0; i < n; ++i) g_pool_busy[dev][idx[i]] = false;
+  }
+};
+
+// lease up to `want` idle pool streams (lowest indices first: a process that never runs two calls at once always gets
+// streams 0 .. want - 1, the round-5 mapping)
+int pool_lease(int want, PoolLease& out) {
   int dev = 0;
   HM_CHECK_HIP(hipGetDevice(&dev));
   if (dev < 0 || dev >= HM_MAX_DEV) { hm_set_error("device index %d beyond the group-stream pool", dev); return -2; }
   std::lock_guard<std::mutex> lk(g_pool_mu);
-  while (g_pool_n[dev] <= g) {
-    hipStream_t s = nullptr;
-    hipError_t e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
-    if (e != hipSuccess) { hm_set_error("creating the stream of instance group %d failed: %s", g_pool_n[dev], hipGetErrorString(e)); return -2; }
-    g_pool[dev][g_pool_n[dev]++] = s;
+  out.dev = dev;
+  for (int g = 0; g < hm_workspace_s::G_MAX && out.n < want; ++g) {
+    if (g < g_pool_n[dev] && g_pool_busy[dev][g]) continue;
+    while (g_pool_n[dev] <= g) {
+      hipStream_t s = nullptr;
+      hipError_t e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+      if (e != hipSuccess) { hm_set_error("creating group stream %d failed: %s", g_pool_n[dev], hipGetErrorString(e)); return -2; }
+      g_pool_busy[dev][g_pool_n[dev]] = false;
+      g_pool[dev][g_pool_n[dev]++] = s;
+    }
+    g_pool_busy[dev][g] = true;
+    out.idx[out.n] = g; out.st[out.n] = g_pool[dev][g]; ++out.n;
   }
-  *out = g_pool[dev][g];
   return 0;
 }
 
@@ -477,10 +501,6 @@ int ensure_group_resources(hm_workspace_s* w, int G) {
   if (!w->have_fork) {
     HM_CHECK_HIP(hipEventCreateWithFlags(&w->ev_fork, hipEventDisableTiming));
     w->have_fork = true;
-  }
-  for (int g = 0; g < G; ++g) {
-    const int rc = pool_stream(g, &w->gstream[g]);      // (re-fetched every call: the workspace may have moved to another device's context)
-    if (rc) return rc;
   }
   while (w->n_gres < G) {
     const int g = w->n_gres;
@@ -830,7 +850,15 @@ extern "C" int hm_optimize_batch(hm_workspace_s* ws, const hm_opt_cfg* cfg, cons
   rc = begin_call(ws, mode == 0);
   if (rc) return rc;
 
-  const int G = group_count(ws, B, dbg);
+  int G = group_count(ws, B, dbg);
+  PoolLease lease;               // released when the call returns (its join events are recorded by then)
+  if (G > 1) {
+    rc = pool_lease(G, lease);
+    if (rc) return rc;
+    G = lease.n >= 2 ? lease.n : 1;
+    while (G > 1 && B / G < 4) --G;
+    for (int g = 0; g < G; ++g) ws->gstream[g] = lease.st[g];
+  }
   if (G == 1) {
     OptRun r;
     r.ws = ws; r.owner = ws; r.bt = *bt; r.dbg = dbg; r.st = st; r.g = 0; r.mode = mode; r.P = P;

@@ -20,10 +20,16 @@ inputs for at most 3 iterations and asserts
   (2) the number of depth rows the reference concatenates per iteration == the oracle's emitted rays V, per iteration,
   (3) H and b of the first solve agree to 1e-5 of their largest entry,
   (4) the final state agrees to 1e-5 (latent: of max(|z|, 1e-3 -- latents start at 0 and stay O(1e-2)); T_ow: of its
-      largest entry) -- or, where the case is ill conditioned, to 3 x the reference's OWN largest response to a relative
-      perturbation of the surface points by +-1e-7 and +-1e-6 (the analytic and the autograd Jacobians differ by fp32
-      rounding, which shows as 1e-7 ... 2e-6 in H and b -- columns eH / eb -- so the matching input disturbance is of that
-      size; printed; such cases are counted and listed, they are not failures of logic).
+      largest entry) -- or, where the case is ill conditioned, to the larger of
+        (i)  3 x the reference's OWN largest response to relative perturbations of its inputs by +-1e-7 and +-1e-6 --
+             surface points, ray directions, depths and the start pose, each element with its own sign (round 6; round 5
+             scaled the surface points only, which under-states the sensitivity of render-dominated cases) -- and
+        (ii) the forward-error bound of the reference's own fp32 solves, sum over its iterations of cond_2(H_i) * 2^-23
+             with H_i the damped normal matrices it hands to torch.inverse (captured): the analytic and the autograd
+             Jacobians differ by fp32 rounding (1e-7 ... 2e-6 in H and b -- columns eH / eb), and an undamped
+             Gauss-Newton case with cond(H) ~ 7e4 (seed 7017) amplifies that to 1e-3 in the state
+             without any difference of logic.
+      Printed; such cases are counted and listed, they are not failures of logic -- checks (1)-(3) stay exact.
 
 Every disagreement is printed with the seed that reproduces it and the script exits non-zero; a disagreement becomes a
 fixture (tests/golden/make_golden_r5.py is where round 5's live).  `tests/test_oracle_vs_reference.py` runs a 24-case
@@ -144,6 +150,35 @@ def build_case(c):
     return p, inst, cfg
 
 
+def perturbed(inst, eps):
+    """The noise probe's input: every float of the surface points, ray directions, depths and the start pose's top three
+    rows multiplied by 1 + eps * (+-1), signs from a fixed stream (eps = 0: the case itself, same arrays)."""
+    if eps == 0.0:
+        return inst
+    rs = np.random.RandomState(4242)
+
+    def j(a):
+        a = np.asarray(a, dtype=np.float32)
+        return (a * (1 + np.float32(eps) * rs.choice([-1.0, 1.0], a.shape).astype(np.float32))).astype(np.float32)
+    out = dict(inst)
+    out["points_w"] = j(inst["points_w"])
+    T = inst["T_ow0"].copy(); T[:3, :] = j(T[:3, :]); out["T_ow0"] = T
+    rd = {k: list(v) for k, v in inst["render"].items()}
+    for k in ("rays_fg", "rays_bg", "depth_fg", "depth_bg"):
+        rd[k] = [j(a) for a in rd[k]]
+    out["render"] = rd
+    return out
+
+
+def cond_bound(cap):
+    """sum_i cond_2(H_i) 2^-23 over the normal matrices the reference inverted (fp64 SVD of the captured fp32 matrices)."""
+    tot = 0.0
+    for H in cap.get("Hs", []):
+        sv = np.linalg.svd(H.numpy().astype(np.float64), compute_uv=False)
+        tot += (sv[0] / max(sv[-1], 1e-300)) * 2.0 ** -23
+    return float(tot)
+
+
 def run_reference(ns, rdec, cfg, inst, pose_known, eps=0.0):
     opt = ns.optimizer.Optimizer(copy.deepcopy(cfg), rdec, None, None)
     rows, cap = [], {}
@@ -155,8 +190,10 @@ def run_reference(ns, rdec, cfg, inst, pose_known, eps=0.0):
         return r
 
     def cap_inverse(A):
-        if A.shape[0] > 4 and "H" not in cap:
-            cap["H"] = A.clone()
+        if A.shape[0] > 4:
+            cap.setdefault("Hs", []).append(A.clone())
+            if "H" not in cap:
+                cap["H"] = A.clone()
         return real_inv(A)
 
     def cap_mv(A, v):
@@ -167,11 +204,12 @@ def run_reference(ns, rdec, cfg, inst, pose_known, eps=0.0):
     ns.optimizer.compute_render_loss = counting
     torch.inverse, torch.mv = cap_inverse, cap_mv
     buf = io.StringIO()
-    pw = (inst["points_w"] * np.float32(1 + eps)).astype(np.float32)
-    rd = {k: [t(a) for a in v] for k, v in inst["render"].items()}
+    pinst = perturbed(inst, eps)
+    pw = pinst["points_w"]
+    rd = {k: [t(a) for a in v] for k, v in pinst["render"].items()}
     try:
         with contextlib.redirect_stdout(buf):
-            z, T, n = opt.shape_pose_joint_opt(t(inst["latent0"].copy()), t(inst["T_ow0"].copy()), rd, t(pw),
+            z, T, n = opt.shape_pose_joint_opt(t(inst["latent0"].copy()), t(pinst["T_ow0"].copy()), rd, t(pw),
                                                inst["cube_radius"], None, pose_known=pose_known)
     finally:
         ns.optimizer.compute_render_loss = real_crl
@@ -210,8 +248,10 @@ def check_case_sdf(ns, seed, tol=1e-5):
     real_inv, real_mv = torch.inverse, torch.mv
 
     def cap_inverse(A):
-        if A.shape[0] > 4 and "H" not in cap:
-            cap["H"] = A.clone()
+        if A.shape[0] > 4:
+            cap.setdefault("Hs", []).append(A.clone())
+            if "H" not in cap:
+                cap["H"] = A.clone()
         return real_inv(A)
 
     def cap_mv(A, v):
@@ -250,11 +290,12 @@ def check_case_sdf(ns, seed, tol=1e-5):
         for eps in (1e-7, -1e-7, 1e-6, -1e-6):
             o2 = ns.optimizer.Optimizer(copy.deepcopy(cfg), rdec, None, None)
             with contextlib.redirect_stdout(io.StringIO()):
-                z2, _, _ = o2.shape_opt_deepsdf(t(z0.copy()), t(inst["T_ow0"].copy()),
-                                                t((inst["points_w"] * np.float32(1 + eps)).astype(np.float32)), None)
+                pi = perturbed(inst, eps)
+                z2, _, _ = o2.shape_opt_deepsdf(t(z0.copy()), t(pi["T_ow0"].copy()), t(pi["points_w"]), None)
             nz = max(nz, rel(z2.numpy(), zr.numpy(), 1e-3))
         rec["noise"] = (nz, 0.0)
-        if rec["ez"] > max(tol, 3 * nz):
+        rec["cond"] = cb = cond_bound(cap)
+        if rec["ez"] > max(tol, 3 * nz, cb):
             fails.append("state")
     rec["fails"] = fails
     return not fails, rec
@@ -296,10 +337,13 @@ def check_case(ns, seed, tol=1e-5, verbose=False):
         # ill conditioned?  measure the reference's own response to a 1e-7 relative input perturbation
         nz = nT = 0.0
         for eps in (1e-7, -1e-7, 1e-6, -1e-6):
-            z2, T2, n2, _, _, _ = run_reference(ns, rdec, cfg, inst, c["pose_known"], eps)
+            z2, T2, n2, _, rows2, _ = run_reference(ns, rdec, cfg, inst, c["pose_known"], eps)
+            if n2 != nr or rows2 != rows_r:
+                continue            # the perturbation moved a discrete decision (a ray in / out of the band): not rounding noise
             nz, nT = max(nz, rel(z2, zr, 1e-3)), max(nT, rel(T2, Tr, 1e-30))
         rec["noise"] = (nz, nT)
-        if rec["ez"] > max(tol, 3 * nz) or rec["eT"] > max(tol, 3 * nT):
+        rec["cond"] = cb = cond_bound(cap)
+        if rec["ez"] > max(tol, 3 * nz, cb) or rec["eT"] > max(tol, 3 * nT, cb):
             fails.append("state")
     rec["fails"], rec["case"] = fails, c
     return not fails, rec
@@ -324,14 +368,14 @@ def main():
                 f"rays {c['n_fg']:3d}+{c['n_bg']:3d} drop {','.join(c['drop'])} known{int(c['pose_known'])} "
                 f"shiftT {max(map(abs, c['T_shift'])):.2f} bias {c['bias_shift']:.3f} | it {r['iter'][0]} {r['reason'][0]:8s} "
                 f"rows {r['rows']} eH {r.get('eH', 0):.1e} eb {r.get('eb', 0):.1e} ez {r['ez']:.1e} eT {r['eT']:.1e}"
-                + (f" noise {r['noise'][0]:.1e}/{r['noise'][1]:.1e}" if r["noise"] else "")
+                + (f" noise {r['noise'][0]:.1e}/{r['noise'][1]:.1e} cond*eps {r.get('cond', 0):.1e}" if r["noise"] else "")
                 + ("" if ok else f"  <-- DISAGREE: {r['fails']} (oracle it {r['iter'][1]} {r['reason'][1]} V {r['V']})"))
         print(line, flush=True)
         lines.append(line)
         noisy += r["noise"] is not None
         if not ok:
             bad.append(s)
-    tail = [f"cases {a.cases}  disagreements {len(bad)} {bad}  state beyond 1e-5 but within 3x the reference's own response to 1e-7 / 1e-6 input perturbations: {noisy}",
+    tail = [f"cases {a.cases}  disagreements {len(bad)} {bad}  state beyond 1e-5 but within max(3x the reference's own response to 1e-7 / 1e-6 input perturbations, sum cond(H) 2^-23): {noisy}",
             f"exit branches reached (reference): {hist}"]
     print("\n".join(tail))
     if a.out:
