@@ -190,6 +190,12 @@ def shipped_config_bench(name, precision, steps=3, warmup=1, n_groups=0):
         # leased group streams per call; HM_SERIAL_GROUPS=1: back to back, the round-5 schedule, for the A/B)
         if len(groups) > 1 and os.environ.get("HM_SERIAL_GROUPS", "0") != "1":
             HO.run_concurrent([(lambda g=g: one(g)) for g in groups])
+        elif os.environ.get("HM_SERIAL_GROUPS") == "2":     # diagnostic: each group alone, synchronised, wall time printed
+            for g in groups:
+                torch.cuda.synchronize(); t = time.perf_counter()
+                one(g)
+                torch.cuda.synchronize()
+                print("# group %s alone: %.1f ms" % (g["yaml"], 1e3 * (time.perf_counter() - t)), file=sys.stderr)
         else:
             for g in groups:
                 one(g)

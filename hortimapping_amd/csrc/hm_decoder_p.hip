@@ -161,6 +161,7 @@ __global__ __launch_bounds__(512, 2) void k_decoder_p(const DecodeArgsP a) {
   constexpr int AH = FWD ? HM_P_AHEAD_FWD : HM_P_AHEAD_BWD;
   __shared__ f16x8 xp[64 * TQP];   // 128 KiB: X[unit][q][8], fp16
   __shared__ float sc[3072];       // 12 KiB scratch: the tile's xyz (forward) / xyz weight columns / lin8 partials + dy / final xyz-gradient sums
+  __shared__ int prog[NWP];        // pacing of the wave pairs of a SIMD (hm_gemm_p.h: PaceP)
   __shared__ float bl[9 * HID];    // 18 KiB: biases of the 8 forward stages (per-instance c0 / c4 included) + lin8's row;
                                    // after the forward stages bl[0 .. 3 * TQP) takes d sdf / d xyz through lin4
 
@@ -214,6 +215,9 @@ __global__ __launch_bounds__(512, 2) void k_decoder_p(const DecodeArgsP a) {
     sc[0 * TQP + tid] = p[0]; sc[1 * TQP + tid] = p[1]; sc[2 * TQP + tid] = p[2];
   }
 
+  if (tid < NWP) prog[tid] = 0;
+  PaceP pc;
+  pc.prog = (lds_int_p*)prog; pc.w = w; pc.done = 0;
   Mask mk = {};                    // masks of the stage's layer: built (forward) or fetched ahead of the K loop (backward)
   f32x16 acc[NRB][NQB];
   // fp16 range guard (see hm_decoder_h.hip), kept on the PACKED fp16 values that go to X: largest stored activation /
@@ -280,6 +284,12 @@ __global__ __launch_bounds__(512, 2) void k_decoder_p(const DecodeArgsP a) {
     const bool trc = g_k1p_trace != nullptr && blockIdx.x == 0 && lane == 0;
 #endif
     HM_STAMP(5 * s + 0);
+#ifdef HM_K1P_TRACE
+    // the constant 100 MHz counter beside the shader clock, at the first and the last stage of the launch: shader clocks per
+    // microsecond = the clock the chip actually sustains under this kernel (DVFS; slots 704 .. 707 of the trace buffer)
+    if (trc && w == 0 && s == (FWD ? 0 : 8)) { g_k1p_trace[704] = wall_clock64(); g_k1p_trace[705] = clock64(); }
+    if (trc && w == 0 && s == (FWD ? 7 : NSTAGE - 1)) { g_k1p_trace[706] = wall_clock64(); g_k1p_trace[707] = clock64(); }
+#endif
 
     if (BWD && (epi == EPI_BWD || epi == EPI_BWD4)) {      // the layer's masks, on their way while the K loop runs
       const u32x4 mv = a.mscr[((size_t)blockIdx.x * 8 + sd.layer) * 512 + 64 * w + fresh_lane_p()];
@@ -300,9 +310,9 @@ __global__ __launch_bounds__(512, 2) void k_decoder_p(const DecodeArgsP a) {
     // of the loop (HM_P_ONE_LOOP = 1: it runs the full loop on the zero weights its stream holds there instead -- one loop
     // instantiation, for builds in which the second one costs registers: +9 k clocks per such stage at L = 256)
     if (u[0] && (u[1] || HM_P_ONE_LOOP)) {
-      k_loop_p<true, true, AH>(acc, a0, a1, a2, a3, ws, sq, n_grp, xp, xo, gst);
+      k_loop_p<true, true, AH>(acc, a0, a1, a2, a3, ws, sq, n_grp, xp, xo, gst, &pc);
     } else if (u[0]) {
-      k_loop_p<true, false, AH>(acc, a0, a1, a2, a3, ws, sq, n_grp, xp, xo);
+      k_loop_p<true, false, AH>(acc, a0, a1, a2, a3, ws, sq, n_grp, xp, xo, nullptr, &pc);
       // the second block's accumulators are not read in this stage: tell the register allocator (no instruction), or 64
       // registers of zeros ride through this loop
 #pragma unroll
@@ -314,6 +324,7 @@ __global__ __launch_bounds__(512, 2) void k_decoder_p(const DecodeArgsP a) {
       if (AH >= 3) { a2.r[0] = wload_p(ws, 0, sn + 4096); a2.r[1] = wload_p(ws, 1, sn + 4096); }
     }
     sq += n_grp * 8192;
+    pc.done += n_grp;
     // the sets beyond the first AH are refilled by the next stage's first steps before anyone reads them: end
     // their live ranges here (no instruction)
     asm volatile("" : "=v"(a3.r[0]), "=v"(a3.r[1]));

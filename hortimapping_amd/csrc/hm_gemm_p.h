@@ -82,13 +82,46 @@ __device__ __forceinline__ void step_p(f32x16 (&acc)[NRB][NQB], const ASetP& a, 
 #endif
 }
 
+// PACING of the two waves of a SIMD (round 6).  Waves w and w + 4 share a SIMD and its matrix pipe; left alone the arbiter
+// serves the older wave first: it finishes a 512 x 512 stage after ~12.3 k clocks, the younger one -- starved while they
+// share, then alone on the pipe at ~70 % of its rate (no partner to fill its operand waits) -- after ~19.8 k, against
+// 16.4 k of matrix work for the pair (shader-clock trace, profiles/r06_k1p_trace_fwd.txt).  The leader's lead only has to
+// cover its own epilogue conversion (~2 k clocks, done in the shadow of the follower's MFMAs); everything beyond that
+// is pipe time lost to the lone-wave tail.  So each wave publishes the number of K-step groups it has started (one LDS
+// word per wave, monotonic across stages) and the FOLLOWER (w >= 4) raises its priority while it is HM_P_LEAD or more
+// groups behind its partner: the pair then advances about one group apart and ends the stage together.
+#ifndef HM_P_PACE
+#define HM_P_PACE 0
+#endif
+#ifndef HM_P_LEAD
+#define HM_P_LEAD 2
+#endif
+typedef __attribute__((address_space(3))) int lds_int_p;
+struct PaceP {
+  lds_int_p* prog;   // LDS: groups started, per wave (relaxed atomics: plain ds_read_b32 / ds_write_b32, counted waits)
+  int w;             // this wave
+  int done;          // groups started before this stage (same in both waves of a pair: stages are barrier-separated)
+};
+__device__ __forceinline__ void pace_p(const PaceP* pc, int g) {
+#if HM_P_PACE
+  if (pc == nullptr) return;
+  const int mine = pc->done + g;
+  const int other = __builtin_amdgcn_readfirstlane(__hip_atomic_load(pc->prog + (pc->w ^ 4), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+  __hip_atomic_store(pc->prog + pc->w, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  if (pc->w >= 4) {
+    if (other - mine >= HM_P_LEAD) __builtin_amdgcn_s_setprio(2);
+    else __builtin_amdgcn_s_setprio(0);
+  }
+#endif
+}
+
 // K loop of one stage: n_grp groups of four steps (statically named ring sets => counted vmcnt waits, no register
 // rotation).  On entry a0 .. a(AH - 1) hold the stage's first steps (fetched by the previous stage's last group, or
 // by the tile prologue); on exit they hold the next stage's.  sq: byte position of the stage's step 0 in the wave's stream.
 template <bool U0, bool U1, int AH>
 __device__ __forceinline__ void k_loop_p(f32x16 (&acc)[NRB][NQB], ASetP& a0, ASetP& a1, ASetP& a2, ASetP& a3,
                                          const WStreamP& ws, int sq, int n_grp, const f16x8* xp, int xo,
-                                         long long* gstamp = nullptr) {
+                                         long long* gstamp = nullptr, const PaceP* pc = nullptr) {
   BSetP b0, b1;
   const f16x8* ph = xp + xo;
 #pragma unroll
@@ -108,6 +141,7 @@ __device__ __forceinline__ void k_loop_p(f32x16 (&acc)[NRB][NQB], ASetP& a0, ASe
 #ifdef HM_K1P_TRACE
     if (gstamp) gstamp[g - 1] = clock64();
 #endif
+    pace_p(pc, g);
     step_p<U0, U1, U0, U1, true>(acc, a0, HM_B0, HM_B1, *S[(0 + AH) & 3], ws, so, ph);
     step_p<U0, U1, U0, U1, true>(acc, a1, HM_B1, HM_B0, *S[(1 + AH) & 3], ws, so + 2048, ph + 2 * TQP);
     step_p<U0, U1, U0, U1, true>(acc, a2, HM_B0, HM_B1, *S[(2 + AH) & 3], ws, so + 4096, ph + 4 * TQP);
@@ -116,10 +150,14 @@ __device__ __forceinline__ void k_loop_p(f32x16 (&acc)[NRB][NQB], ASetP& a0, ASe
     ph += 8 * TQP;
   }
   // last group: the fetches that run past the stage's end are the NEXT stage's first steps (both row blocks)
+  pace_p(pc, n_grp);
   step_p<U0, U1, (0 + AH < 4 ? U0 : true), (0 + AH < 4 ? U1 : true), true>(acc, a0, HM_B0, HM_B1, *S[(0 + AH) & 3], ws, so, ph);
   step_p<U0, U1, (1 + AH < 4 ? U0 : true), (1 + AH < 4 ? U1 : true), true>(acc, a1, HM_B1, HM_B0, *S[(1 + AH) & 3], ws, so + 2048, ph + 2 * TQP);
   step_p<U0, U1, (2 + AH < 4 ? U0 : true), (2 + AH < 4 ? U1 : true), true>(acc, a2, HM_B0, HM_B1, *S[(2 + AH) & 3], ws, so + 4096, ph + 4 * TQP);
   step_p<U0, U1, true, true, false>(acc, a3, HM_B1, HM_B0, *S[(3 + AH) & 3], ws, so + 6144, ph);
+#if HM_P_PACE
+  if (pc != nullptr) __builtin_amdgcn_s_setprio(0);
+#endif
 #undef HM_B0
 #undef HM_B1
 }

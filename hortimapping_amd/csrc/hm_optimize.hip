@@ -411,6 +411,10 @@ extern "C" int hm_workspace_create(hm_decoder_s* dec, const hm_limits* lim, hm_w
   hipError_t e = hipMalloc(&w->d_blob, w->blob_bytes);
   if (e != hipSuccess) { hm_set_error("hipMalloc(%zu) failed: %s", w->blob_bytes, hipGetErrorString(e)); delete w; return -2; }
   e = hipMemset(w->d_blob, 0, w->blob_bytes);
+  // the fill runs on the NULL stream and may still be in flight when hipMemset returns; a caller on a NON-BLOCKING stream
+  // (torch side streams: optimizer.py run_concurrent) is not ordered behind it -- its first kernels then raced the fill
+  // (round 6: iteration counts of 0 / 2 instead of 8).  Wait for it here, once per workspace.
+  if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
   if (e != hipSuccess) { hm_set_error("hipMemset failed: %s", hipGetErrorString(e)); (void)hipFree(w->d_blob); delete w; return -2; }
   Carver c;
   c.mode = Carver::CARVE;
@@ -546,7 +550,10 @@ extern "C" int hm_workspace_profile_read(hm_workspace_s* w, double* ms_total, lo
 extern "C" int hm_workspace_counters(hm_workspace_s* w, int enable) {
   if (w == nullptr) { hm_set_error("null workspace"); return -1; }
   w->count_on = enable;
-  if (enable) HM_CHECK_HIP(hipMemset(w->d_counters, 0, hm_workspace_s::G_MAX * N_COUNTER * sizeof(unsigned long long)));
+  if (enable) {
+    HM_CHECK_HIP(hipMemset(w->d_counters, 0, hm_workspace_s::G_MAX * N_COUNTER * sizeof(unsigned long long)));
+    HM_CHECK_HIP(hipStreamSynchronize(nullptr));          // (NULL-stream fill: see hm_workspace_create)
+  }
   return 0;
 }
 
@@ -599,7 +606,10 @@ extern "C" int hm_workspace_screening_stats(hm_workspace_s* w, int reset, long l
       for (int g = 0; g < hm_workspace_s::G_MAX; ++g) out4[k] += all[g * 4 + k];
     }
   }
-  if (reset) HM_CHECK_HIP(hipMemset(w->d_screen_stats, 0, N * sizeof(unsigned long long)));
+  if (reset) {
+    HM_CHECK_HIP(hipMemset(w->d_screen_stats, 0, N * sizeof(unsigned long long)));
+    HM_CHECK_HIP(hipStreamSynchronize(nullptr));          // (NULL-stream fill: see hm_workspace_create)
+  }
   return 0;
 }
 

@@ -11,6 +11,8 @@ from __future__ import annotations
 import ctypes
 import json
 import os
+import threading
+from typing import Optional
 
 import numpy as np
 
@@ -108,7 +110,11 @@ class HmDecoderArch(ctypes.Structure):
 class DecoderWeights:
     """Owns an `hm_decoder_t` handle (device-resident packed weights)."""
 
-    def __init__(self, Ws, bs, latent_dim: int, ln=None, use_tanh: bool = False, force_generic: bool = False):
+    def __init__(self, Ws, bs, latent_dim: int, ln=None, use_tanh: bool = False, force_generic: bool = False,
+                 precision: Optional[str] = None):
+        """`precision`: None = the process default (HM_PRECISION, else exact f32); a name = that arithmetic whatever the
+        environment says (what `f32_twin` passes: it must not touch process-global state)."""
+        self._twin_lock = threading.Lock()
         self.latent_dim = int(latent_dim)
         L = self.latent_dim
         self.Ws = [np.ascontiguousarray(w, dtype=np.float32) for w in Ws]
@@ -151,9 +157,12 @@ class DecoderWeights:
             _lib.check(lib.hm_decoder_create_arch(ctypes.byref(arch), Wp, bp, gp, ep, ctypes.byref(h)),
                        "hm_decoder_create_arch")
         self.handle = h
-        default = os.environ.get("HM_PRECISION", "")
-        if default and (not self.generic or default in ("f32", "f16x3")):   # any-architecture handles: f32 and f16x3 only
-            self.set_precision(default)
+        if precision is not None:
+            self.set_precision(precision)
+        else:
+            default = os.environ.get("HM_PRECISION", "")
+            if default and (not self.generic or default in ("f32", "f16x3")):   # any-architecture handles: f32 and f16x3 only
+                self.set_precision(default)
 
     PRECISIONS = {"f32": 0, "f16x3": 1, "f16x3f_f16b": 2, "f16": 3}
 
@@ -177,15 +186,12 @@ class DecoderWeights:
         of any other thread using the decoder in that window."""
         if self.precision == "f32":
             return self
-        tw = getattr(self, "_f32_twin", None)
-        if tw is None:
-            env = os.environ.pop("HM_PRECISION", None)          # the twin is f32 whatever the process default says
-            try:
-                tw = DecoderWeights(self.Ws, self.bs, self.latent_dim, self.ln, self.use_tanh, self.generic)
-            finally:
-                if env is not None:
-                    os.environ["HM_PRECISION"] = env
-            self._f32_twin = tw
+        with self._twin_lock:                       # two threads asking at once share ONE twin
+            tw = getattr(self, "_f32_twin", None)
+            if tw is None:
+                tw = DecoderWeights(self.Ws, self.bs, self.latent_dim, self.ln, self.use_tanh, self.generic,
+                                    precision="f32")   # f32 whatever the process default says
+                self._f32_twin = tw
         return tw
 
     @classmethod

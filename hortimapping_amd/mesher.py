@@ -130,9 +130,21 @@ class MeshExtractor(object):
         n = self.voxels_dim
         return y[:, :n3].reshape(B, n, n, n)
 
-    def extract_meshes(self, latents: torch.Tensor) -> List[TriangleMesh]:
-        soups = extract_surface(self.decode_grids(latents), self.cube_radius, method=self.method)
-        return [TriangleMesh(*weld(s)) for s in soups]
+    def extract_meshes(self, latents: torch.Tensor, chunk: int = 0) -> List[TriangleMesh]:
+        """Meshes of all `latents`, `chunk` fruits per grid-decode + marching-cubes launch (0 = automatic: as many as keep
+        the launch's buffers -- 16 bytes of query point + 4 of sdf per voxel, plus the triangle buffer -- under ~2 GiB, at most
+        256): memory no longer grows with the number of fruits of a sequence (at voxels_dim = 128 the points
+        alone are 33 MB per fruit).  Every fruit's mesh is independent of the chunking."""
+        lat = latents.reshape(-1, self.decoder.latent_dim)
+        B = lat.shape[0]
+        if chunk <= 0:
+            per_fruit = 24 * self.voxels_dim ** 3 + 36 * 16 * self.voxels_dim ** 2
+            chunk = int(max(1, min(256, (2 << 30) // per_fruit)))
+        out: List[TriangleMesh] = []
+        for b0 in range(0, B, chunk):
+            soups = extract_surface(self.decode_grids(lat[b0:b0 + chunk]), self.cube_radius, method=self.method)
+            out += [TriangleMesh(*weld(s)) for s in soups]
+        return out
 
     def extract_mesh_from_code(self, code):
         """mesher.py:14-24 -> dict with `vertices` (float32) and `faces` (int32)."""

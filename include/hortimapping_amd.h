@@ -85,7 +85,13 @@ int hm_decoder_create_arch(const hm_decoder_arch* arch, const float* const* W, c
  *      ~2^-22 relative accuracy (fp32 class), 16/3 x the MFMA rate.  Hidden activations and back-propagated
  *      gradients are held as fp16 hi/lo pairs, so they must stay below 65504 in magnitude; a 64-query tile that
  *      exceeds it returns NaN sdf / Jacobian rows (never silent garbage) and hm_optimize_batch ends that instance
- *      with HM_STATUS_SOLVE_FAILED.  Mode 0 has no such limit.
+ *      with HM_STATUS_SOLVE_FAILED.  Mode 0 has no such limit.  Granularity of the poison = one 64-query tile: the
+ *      tiles of the surface points and of the forward ray samples never span two instances, but the render term's
+ *      Jacobian samples of ALL instances are packed into one list (one backward-only launch), so a tile there can
+ *      hold the last samples of instance b and the first of b + 1: a BACKWARD overflow of one of them then fails
+ *      both (the neighbour ends with HM_STATUS_SOLVE_FAILED too; its result is not wrong, it is withheld).  This is
+ *      the one exception to "a batched result equals the single-instance result bit for bit"; the drop-in
+ *      Optimizer class reruns every failed instance in mode 0, where the statement holds without exception.
  *   2  "f16x3f_f16b" (mixed, NOT fp32-class; BASELINE.json configs[4] "fp16 MFMA decoder"): the forward stages --
  *      residuals, ReLU masks, sdf -- as mode 1, the eight input-gradient (backward) stages in ONE fp16 MFMA pass on the
  *      hi parts: 4 instead of 6 matrix passes per query; Jacobian rows carry ~2^-11 relative rounding per layer.

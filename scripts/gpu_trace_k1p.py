@@ -22,12 +22,13 @@ lib = _lib.lib()
 lib.hm_debug_set_k1p_trace.argtypes = [ctypes.c_void_p]
 for _ in range(3):
     ops.decode_batch(dec, lat, pts4, nq, mode=mode, pose_dim=7)
-tr = torch.zeros(8 * 80 + 64, dtype=torch.int64, device="cuda")
+tr = torch.zeros(8 * 80 + 64 + 4, dtype=torch.int64, device="cuda")
 lib.hm_debug_set_k1p_trace(tr.data_ptr())
 ops.decode_batch(dec, lat, pts4, nq, mode=mode, pose_dim=7)
 torch.cuda.synchronize()
 lib.hm_debug_set_k1p_trace(None)
-G = tr.cpu().numpy()[640:].reshape(8, 8)
+G = tr.cpu().numpy()[640:704].reshape(8, 8)
+C = tr.cpu().numpy()[704:708]
 T = tr.cpu().numpy()[:640].reshape(8, 16, 5)
 ns = 8 if mode == 0 else 16
 t = T[0]
@@ -40,6 +41,9 @@ for s in range(ns):
     starts = " ".join(f"{int(T[w, s, 1] - k0):5d}" for w in range(8))
     print(f"{s:3d} {t[s,1]-t[s,0]:10d} {t[s,2]-t[s,1]:10d} {t[s,3]-t[s,2]:9d} {t[s,4]-t[s,3]:10d}   | {nxt - t[s,0]:8d}   ends {ends}   starts {starts}")
 print("tile total", t[ns - 1, 4] - t[0, 0])
+if C[2] > C[0]:
+    print(f"sustained shader clock between the first and the last stage entry of this launch: {(C[3] - C[1]) / ((C[2] - C[0]) / 100.0):.0f} MHz "
+          f"({C[3] - C[1]} shader clocks in {(C[2] - C[0]) / 100.0:.1f} us of the 100 MHz counter; mode 1 = the last launch = backward only)")
 if G.any():
     print("stage 1, K-loop group starts (4 steps = 32 MFMAs per group) relative to the first wave's K-loop start:")
     k0 = T[:, 1, 1].min()

@@ -354,7 +354,12 @@ def test_instance_groups_share_one_generic_decoder_without_sharing_scratch(table
         dec = DecoderWeights.from_module(_MiniDecoder(p, True, False)).set_precision(arith)
     assert dec.generic
     L = int(p["latent_dim"])
-    protos = _instances(p, range(5), n_pts=200, n_frames=1, n_fg=40, n_bg=40)
+    # geometry from the analytic table in both cases: the LayerNorm table is a RANDOM function (make_arch_decoder cannot
+    # build a fruit with LayerNorm), ray-marching it for surface points never finds enough hits -- this test sat in that
+    # loop until the suite's limit killed it (round 6).  The LayerNorm table runs the shape-only loop (forward + backward
+    # through the LayerNorm saves, the scratch in question) on those points; the weight-normed table the joint loop.
+    mode = 1 if table == "layernorm" else 0
+    protos = _instances(_analytic_arch(), range(5), n_pts=200, n_frames=1, n_fg=40, n_bg=40)
     insts = [W.to_instance(protos[i % 5], pose_known=bool(i % 2)) for i in range(20)]
     opt = W.c2_opt_cfg(max_iter=3, n_sample_on_ray=16, n_frame=1)
     hcfg = HO.opt_cfg_from_dict(opt)
@@ -365,7 +370,7 @@ def test_instance_groups_share_one_generic_decoder_without_sharing_scratch(table
     for groups in (1, 2, 4, 2):
         ws.set_groups(groups)
         pb.latent.copy_(init[0]); pb.T_ow.copy_(init[1])
-        HO.run_packed(ws, hcfg, pb, 0)
+        HO.run_packed(ws, hcfg, pb, mode)
         res = (pb.latent.clone(), pb.T_ow.clone(), pb.iter_count.clone(), pb.status.clone())
         if groups in out:
             assert all(torch.equal(x, y) for x, y in zip(out[groups], res))          # run to run
