@@ -665,7 +665,7 @@ def main(argv=None, emit=True):
                 "configs4_lab_pepper_berry", "f16", 3, 1).items() if k in ("value", "unit", "ms_per_fruit", "dtype", "steps")}
             out["configs4_lab_pepper_berry"]["plain_f16"]["note"] = (
                 "BASELINE.json configs[4] names the plain-fp16 MFMA decoder: fp16-class results, labelled, never the line")
-    if not stub:
+    if not stub and out is not None:       # (only rank 0 holds the line)
         # the driver's parsed record keeps `config` and `roofline` only: the three readings of the metric and the labelled
         # secondary workloads ride in `config` as plain numbers (instances/s), next to the full objects of the line
         rd = {k: out[k]["value"] for k in ("c2_sdf", "c2_joint2048", "exact_f32", "mixed_f16x3f_f16b", "plain_f16", "trained_decoder",

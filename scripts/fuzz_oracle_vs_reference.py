@@ -112,11 +112,15 @@ def draw_case(seed):
     return c
 
 
-def build_case(c):
+def build_case(c, inst=None):
+    """(decoder parameters, instance, config) of a drawn case.  `inst`: the finished instance from a fixture (the numpy ray
+    marching below is most of a case's time; tests/golden/g19_fuzz_oracle.npz carries the instances of its seeds)."""
     p, (Ws, bs) = base_decoder(c["L"])
     if c["bias_shift"] != 0.0:
         p = {k: (v.copy() if hasattr(v, "copy") else v) for k, v in p.items()}
         p["lin8.bias"] = (p["lin8.bias"] + np.float32(c["bias_shift"])).astype(np.float32)
+    if inst is not None:
+        return p, inst, case_cfg(c)
     inst = S.make_instance(Ws, bs, c["L"], c["inst_id"], n_pts=c["n_pts"], n_frames=c["n_frames"], n_fg=c["n_fg"],
                            n_bg=c["n_bg"], r_max=0.08)
     rs = np.random.RandomState(c["bg_seed"])
@@ -139,6 +143,10 @@ def build_case(c):
     T0 = inst["T_ow0"].copy()
     T0[:3, 3] += np.asarray(c["T_shift"], dtype=np.float32)
     inst["T_ow0"] = T0
+    return p, inst, case_cfg(c)
+
+
+def case_cfg(c):
     o = copy.deepcopy(O.default_opt_cfg())
     o["scale_on"] = c["scale_on"]
     o["lm"].update(lm_on=c["lm_on"], lm_eye=c["lm_eye"])
@@ -146,8 +154,7 @@ def build_case(c):
                        occlusion_on=c["occlusion"], n_frame=10)
     o["converge"].update(max_iter=c["max_iter"], **c["eps"])
     o["robust_iter"] = c["robust_iter"]
-    cfg = {"device": "cpu", "opt": o, "vis": {"vis_pause_s": 0, "log_on": True, "vis_on": False}}
-    return p, inst, cfg
+    return {"device": "cpu", "opt": o, "vis": {"vis_pause_s": 0, "log_on": True, "vis_on": False}}
 
 
 def perturbed(inst, eps):

@@ -8,8 +8,9 @@ Seeds 3000-3079: disjoint from every range the oracle itself was fuzzed on again
 profiles/r06_oracle_fuzz.txt; 2000-2059 was round 5's GPU range).  Per seed: the oracle's result on the case and on its two
 +-1e-6 probes (final latent / pose, iteration count, exit branch, the last iteration's (ball-valid, Jacobian, emitted-ray)
 counts) and sum_i cond_2(H_i) 2^-23 over the normal matrices of its solves (the forward-error bound of an fp32 solve; the
-state tolerance of the test is max(2e-4, 3 x probe response, that bound)).  Inputs are NOT stored: the test rebuilds them from
-the seed with the same generator (scripts/fuzz_oracle_vs_reference.py: draw_case / build_case, numpy RandomState streams)."""
+state tolerance of the test is max(2e-4, 3 x probe response, that bound)).  the instances (a few KB each) ARE stored too,
+because building one is a numpy ray-march of the synthetic fruit that took the GPU box 2 s per case; decoder parameters and
+option blocks are rebuilt from the seed (scripts/fuzz_oracle_vs_reference.py: draw_case / build_case(c, inst))."""
 import os
 import sys
 
@@ -47,6 +48,12 @@ def main():
     for seed in SEEDS:
         c = F.draw_case(seed)
         p, inst, cfg = F.build_case(c)
+        out[f"in_{seed}_latent0"], out[f"in_{seed}_T_ow0"] = inst["latent0"], inst["T_ow0"]
+        out[f"in_{seed}_points_w"], out[f"in_{seed}_cube_radius"] = inst["points_w"], np.float64(inst["cube_radius"])
+        for k, v in inst["render"].items():
+            for f, a in enumerate(v):
+                out[f"in_{seed}_{k}_{f}"] = np.asarray(a)
+        out[f"in_{seed}_n_frames"] = np.int64(len(inst["render"]["T_wc"]))
         for tag, eps in (("0", 0.0), ("p", 1e-6), ("m", -1e-6)):
             z, T, n, reason, last, cb = run(p, cfg, inst, c["pose_known"], eps)
             out[f"z_{seed}_{tag}"] = z.astype(np.float32)

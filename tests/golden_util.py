@@ -113,3 +113,63 @@ def traj_noise(tag):
             a = np.abs(g[tag])
             return float(a[:, 0].max()), float(a[:, 1].max()), float(a[:, 2].max())
     return 0.0, 0.0, 0.0
+
+
+# ------------------------------------------------------------------------------------------------ oracle-result cache
+# Round 6: the GPU suite spent ~5 of its 13 minutes running the CPU oracle on the GPU box's host.
+# Several of those runs are on inputs the GPU path itself prepares (ray-marched synthetic fruits, the entry points' device
+# data preparation), so they cannot be generated in the build container -- but they ARE bit-reproducible from box to box.
+# `oracle_joint_cached` keys the oracle's result by a SHA-256 of everything it depends on (folded decoder weights, option
+# block, every input array, flags); results recorded on a GPU box (HM_ORACLE_RECORD=<dir>, then copied here) are
+# committed under tests/golden/oracle_cache/.  A key that is not there -- a changed generator, a changed option -- is
+# simply computed, as before: the cache can make the suite faster, never wrong (a stale entry cannot be hit: its key
+# covers the inputs bit for bit; the oracle's own code is pinned by the CPU tier against the reference-made fixtures).
+ORACLE_CACHE = os.path.join(GOLDEN_DIR, "oracle_cache")
+ORACLE_CACHE_STATS = {"hit": 0, "miss": 0}
+
+
+def _digest(h, x):
+    import torch
+    if isinstance(x, torch.Tensor):
+        x = x.detach().cpu().numpy()
+    if isinstance(x, np.ndarray):
+        a = np.ascontiguousarray(x)
+        h.update(str(a.dtype).encode()); h.update(str(a.shape).encode()); h.update(a.tobytes())
+    elif isinstance(x, dict):
+        for k in sorted(x):
+            h.update(str(k).encode()); _digest(h, x[k])
+    elif isinstance(x, (list, tuple)):
+        h.update(b"["); [_digest(h, v) for v in x]; h.update(b"]")
+    else:
+        h.update(repr(x).encode())
+
+
+def oracle_joint_cached(od, opt, latent0, T_ow0, render, points_w, cube_radius, pose_known, shape_only=False):
+    """`oracle.hm_oracle.shape_pose_joint_opt` (or `shape_opt_deepsdf`) -> (z, T, n) as (np.float32, np.float32, int),
+    from tests/golden/oracle_cache/ when this exact call has been recorded."""
+    import hashlib
+    import torch
+    from oracle import hm_oracle as O
+    as_t = lambda a: a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(a))
+    h = hashlib.sha256()
+    _digest(h, ["v1", str(od.dtype), list(od.Ws), list(od.bs), od.cat, od.ln, od.use_tanh, opt, latent0, T_ow0,
+                None if shape_only else render, points_w, float(cube_radius), bool(pose_known), bool(shape_only)])
+    key = h.hexdigest()[:24]
+    path = os.path.join(ORACLE_CACHE, key + ".npz")
+    if os.path.exists(path):
+        g = np.load(path)
+        ORACLE_CACHE_STATS["hit"] += 1
+        return g["z"], g["T"], int(g["n"])
+    ORACLE_CACHE_STATS["miss"] += 1
+    if shape_only:
+        z, T, n = O.shape_opt_deepsdf(od, opt, as_t(latent0).clone(), as_t(T_ow0).clone(), as_t(points_w))
+    else:
+        rd = {k: [as_t(a) for a in v] for k, v in render.items()}
+        z, T, n = O.shape_pose_joint_opt(od, opt, as_t(latent0).clone(), as_t(T_ow0).clone(), rd, as_t(points_w), cube_radius,
+                                         pose_known=pose_known)
+    z, T, n = z.numpy().astype(np.float32), T.numpy().astype(np.float32), int(n)
+    rec = os.environ.get("HM_ORACLE_RECORD", "")
+    if rec:
+        os.makedirs(rec, exist_ok=True)
+        np.savez(os.path.join(rec, key + ".npz"), z=z, T=T, n=np.int64(n))
+    return z, T, n

@@ -44,6 +44,16 @@ _ORACLE = {}        # (seed, eps) -> oracle outcome: the oracle does not depend 
                     # second parametrisation reuses the first one's runs (three oracle runs per case are most of this test's time)
 
 
+def _fixture_instance(seed):
+    g = _fixture()
+    if g is None or f"in_{seed}_latent0" not in g.files:
+        return None
+    F_ = int(g[f"in_{seed}_n_frames"])
+    rd = {k: [g[f"in_{seed}_{k}_{f}"] for f in range(F_)] for k in ("T_wc", "rays_fg", "rays_bg", "depth_fg", "depth_bg")}
+    return {"latent0": g[f"in_{seed}_latent0"], "T_ow0": g[f"in_{seed}_T_ow0"], "points_w": g[f"in_{seed}_points_w"],
+            "cube_radius": float(g[f"in_{seed}_cube_radius"]), "render": rd}
+
+
 def _oracle_cached(F, seed, p, cfg, inst, pose_known, eps=0.0):
     key = (seed, eps)
     if key not in _ORACLE:
@@ -86,7 +96,7 @@ def test_hip_path_equals_oracle_on_random_small_cases(precision):
     for seed in SEEDS:
         c = F.draw_case(seed)
         if seed not in _CASES:
-            _CASES[seed] = F.build_case(c)          # numpy ray marching of the synthetic fruit: most of a case's time
+            _CASES[seed] = F.build_case(c, _fixture_instance(seed))   # (without the fixture: numpy ray marching, 2 s per case)
         p, inst, cfg = _CASES[seed]
         key = (c["L"], c["bias_shift"])
         if key not in decs:

@@ -102,7 +102,9 @@ def test_host_pacing_off_is_a_pure_enqueue_with_the_same_bits(precision):
     Ws, bs = S.fold_weight_norm(p)
     dec = DecoderWeights.from_params(p).set_precision(precision)
     if not _PACING_INSTANCES:
-        _PACING_INSTANCES.extend(S.make_instance(Ws, bs, 32, i, n_pts=512, n_frames=2, n_fg=64, n_bg=64) for i in range(20))
+        fac = W.gpu_sdf_factory(DecoderWeights.from_params(p).set_precision("f32"))   # (the numpy forward took 30 s here)
+        _PACING_INSTANCES.extend(S.make_instance(Ws, bs, 32, i, n_pts=512, n_frames=2, n_fg=64, n_bg=64, sdf_fn_factory=fac)
+                                 for i in range(20))
     insts = [W.to_instance(d) for d in _PACING_INSTANCES]
     from oracle import hm_oracle as O
     opt = O.default_opt_cfg()                       # wild_pepper.yaml block: every epsilon > 0, max_iter 50
