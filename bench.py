@@ -250,7 +250,7 @@ def shipped_config_bench(name, precision, steps=3, warmup=1, n_groups=0):
             "roofline_step": {"algorithmic_flop_per_step": int(A), "achieved": round(ach, 2), "peak": peak,
                               "unit": "TFLOP/s", "frac": round(ach / peak, 4), "ms_per_step": round(dt * 1e3, 3)},
             "data": "synthetic fruits (%d distinct per group, replicated), analytic L = 32 decoder" % SHIPPED_DISTINCT,
-            "profile": "profiles/r05_%s_kernel_stats.txt (rocprofv3 --kernel-trace --stats of `bench.py --shipped-only %s`)" % (name, name)}
+            "profile": "profiles/r06_%s_kernel_stats.txt (rocprofv3 --kernel-trace --stats of `bench.py --shipped-only %s`)" % (name, name)}
 
 
 def parse_args(argv=None):

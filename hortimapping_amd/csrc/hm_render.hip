@@ -164,39 +164,71 @@ __global__ __launch_bounds__(256) void k_sample_rays(const RenderCfg cfg, const 
 // ("dead").  One wavefront per ray, lane = depth sample; cpos is rewritten from "slot in ptsRc" to "slot in the promoted
 // list ptsRp" or a CPOS_FAR_* code that k_ray_scan turns into a saturated sdf.  Bit-identical results by construction;
 // tests/test_gpu_round5.py compares whole trajectories with the screening off and counts violations in verify mode.
-// Sixteen rays per 1024-thread workgroup: the promoted samples of the whole workgroup take their slots with ONE atomic
-// on the instance counter (one per wave cost 1.1 ms per iteration on the challenge configuration: 96 k atomics on 64 words).
+// Sixty-four rays per 1024-thread workgroup, four per wave (round 6): the four rays' loads are in flight together, their
+// ballots stay in registers, and the promoted samples of the whole workgroup take their slots with ONE atomic on the
+// instance counter -- 25 atomics per instance and iteration on the challenge configuration (one per wave cost 1.1 ms per
+// iteration there: 96 k atomics on 64 words; one per 16 rays 0.55 ms; this form: see profiles/r06_configs2_*).
+constexpr int PROMOTE_RPW = 4;
 __global__ __launch_bounds__(1024) void k_promote(const RenderCfg cfg, const RenderBuffers rb,
                                                   const int* __restrict__ active) {
   __shared__ int wcnt[16];
   __shared__ int base_s;
   const int b = blockIdx.z, f = blockIdx.y;
   const int wv = threadIdx.x >> 6;
-  const int r = blockIdx.x * 16 + wv;
   const int lane = threadIdx.x & 63;
   if (active != nullptr && active[b] == 0) return;                 // (workgroup-uniform exits)
   if (f >= rb.n_frames[b]) return;
   const int nray = rb.n_fg[b * cfg.F + f] + rb.n_bg[b * cfg.F + f];
-  const bool ray_ok = r < cfg.R && r < nray;
   // a frame with too few ball-valid samples is skipped by k_ray_scan (loss.py:43-45): none of its samples is needed
   const bool frame_ok = rb.valid_count[b * cfg.F + f] >= cfg.min_valid;
   const int M = cfg.M;
-  const size_t at = (size_t)b * rb.nR_stride + (size_t)(f * cfg.R + (ray_ok ? r : 0)) * M + lane;
-  const bool in = ray_ok && lane < M;
-  int slot = CPOS_NOT_VALID;
-  if (in) slot = rb.cpos[at];
-  const bool valid = in && slot >= 0;                 // k_sample_rays: slot >= 0 <=> ball-valid (w of ptsR is 1)
-  const float st = valid ? rb.sdfS[(size_t)b * rb.nR_stride + slot] : 0.f;
   const float lim = cfg.occ_th + cfg.screen_eps;
-  const bool far_in = valid && st < -lim, far_out = valid && st > lim;
-  const unsigned long long m_in = __ballot(far_in);
-  const int first_in = m_in ? __ffsll((long long)m_in) - 1 : 64;
-  // (a sample whose screening value is not finite is never dead: it is promoted, so that the range guard of the f16x3
-  // forward reports it exactly as it did before the screening existed)
-  const bool dead = valid && lane > first_in && isfinite(st);
-  const bool promote = valid && frame_ok && !dead && !far_in && !far_out;     // includes non-finite screening values
-  const unsigned long long pm = __ballot(promote);
-  if (lane == 0) wcnt[wv] = __popcll(pm);
+  const size_t ibase = (size_t)b * rb.nR_stride;
+  const int r0 = (blockIdx.x * 16 + wv) * PROMOTE_RPW;              // this wave's rays: r0 .. r0 + 3
+  size_t at[PROMOTE_RPW];
+  int slot[PROMOTE_RPW];
+  float st[PROMOTE_RPW];
+  bool in[PROMOTE_RPW];
+#pragma unroll
+  for (int i = 0; i < PROMOTE_RPW; ++i) {
+    const int r = r0 + i;
+    const bool ray_ok = r < cfg.R && r < nray;
+    at[i] = ibase + (size_t)(f * cfg.R + (ray_ok ? r : 0)) * M + lane;
+    in[i] = ray_ok && lane < M;
+    slot[i] = in[i] ? rb.cpos[at[i]] : CPOS_NOT_VALID;
+  }
+#pragma unroll
+  for (int i = 0; i < PROMOTE_RPW; ++i)                    // k_sample_rays: slot >= 0 <=> ball-valid (w of ptsR is 1)
+    st[i] = slot[i] >= 0 ? rb.sdfS[ibase + slot[i]] : 0.f;
+  unsigned long long pm[PROMOTE_RPW], fm[PROMOTE_RPW];
+  int mine = 0;
+  int n_valid = 0, n_dead = 0, n_bad = 0;
+#pragma unroll
+  for (int i = 0; i < PROMOTE_RPW; ++i) {
+    const bool valid = slot[i] >= 0;
+    const bool far_in = valid && st[i] < -lim, far_out = valid && st[i] > lim;
+    const unsigned long long m_in = __ballot(far_in);
+    const int first_in = m_in ? __ffsll((long long)m_in) - 1 : 64;
+    // (a sample whose screening value is not finite is never dead: it is promoted, so that the range guard of the f16x3
+    // forward reports it exactly as it did before the screening existed)
+    const bool dead = valid && lane > first_in && isfinite(st[i]);
+    const bool promote = valid && frame_ok && !dead && !far_in && !far_out;     // includes non-finite screening values
+    pm[i] = __ballot(promote);
+    fm[i] = __ballot(far_in || dead);
+    mine += __popcll(pm[i]);
+    if (rb.screen_stats != nullptr) {
+      bool bad = false;
+      if (rb.sdfFull != nullptr && valid && frame_ok && !promote) {
+        const float ex = rb.sdfFull[ibase + slot[i]];
+        if (far_in && lane == first_in) bad = !(ex < -cfg.occ_th);             // must really saturate to occupancy 1
+        else if (!dead && !far_in) bad = !(ex > cfg.occ_th);                   // far outside: must really be occupancy 0
+      }
+      n_valid += __popcll(__ballot(valid && frame_ok));
+      n_dead += __popcll(__ballot(dead && frame_ok));
+      n_bad += __popcll(__ballot(bad));
+    }
+  }
+  if (lane == 0) wcnt[wv] = mine;
   __syncthreads();
   if (threadIdx.x == 0) {
     int tot = 0;
@@ -207,30 +239,26 @@ __global__ __launch_bounds__(1024) void k_promote(const RenderCfg cfg, const Ren
   __syncthreads();
   int base = base_s;
   for (int i = 0; i < wv; ++i) base += wcnt[i];
-  if (valid) {
-    int code;
-    if (promote) {
-      code = base + __popcll(pm & ((1ull << lane) - 1ull));
-      reinterpret_cast<f32x4*>(rb.ptsRp)[(size_t)b * rb.nR_stride + code] = reinterpret_cast<const f32x4*>(rb.ptsR)[at];
-    } else {
-      code = (far_in || dead) ? CPOS_FAR_INSIDE : CPOS_FAR_OUTSIDE;          // (!frame_ok: the code is never read)
+  const unsigned long long below = (1ull << lane) - 1ull;
+#pragma unroll
+  for (int i = 0; i < PROMOTE_RPW; ++i) {
+    if (slot[i] >= 0) {
+      int code;
+      if ((pm[i] >> lane) & 1ull) {
+        code = base + __popcll(pm[i] & below);
+        reinterpret_cast<f32x4*>(rb.ptsRp)[ibase + code] = reinterpret_cast<const f32x4*>(rb.ptsR)[at[i]];
+      } else {
+        code = ((fm[i] >> lane) & 1ull) ? CPOS_FAR_INSIDE : CPOS_FAR_OUTSIDE;  // (!frame_ok: the code is never read)
+      }
+      rb.cpos[at[i]] = code;
     }
-    rb.cpos[at] = code;
+    base += __popcll(pm[i]);
   }
-  if (rb.screen_stats != nullptr) {
-    bool bad = false;
-    if (rb.sdfFull != nullptr && valid && frame_ok && !promote) {
-      const float ex = rb.sdfFull[(size_t)b * rb.nR_stride + slot];
-      if (far_in && lane == first_in) bad = !(ex < -cfg.occ_th);             // must really saturate to occupancy 1
-      else if (!dead && !far_in) bad = !(ex > cfg.occ_th);                   // far outside: must really be occupancy 0
-    }
-    const unsigned long long vm = __ballot(valid && frame_ok), dm = __ballot(dead && frame_ok), bm = __ballot(bad);
-    if (lane == 0) {
-      if (vm) atomicAdd(&rb.screen_stats[0], (unsigned long long)__popcll(vm));
-      if (pm) atomicAdd(&rb.screen_stats[1], (unsigned long long)__popcll(pm));
-      if (bm) atomicAdd(&rb.screen_stats[2], (unsigned long long)__popcll(bm));
-      if (dm) atomicAdd(&rb.screen_stats[3], (unsigned long long)__popcll(dm));
-    }
+  if (rb.screen_stats != nullptr && lane == 0) {
+    if (n_valid) atomicAdd(&rb.screen_stats[0], (unsigned long long)n_valid);
+    if (mine) atomicAdd(&rb.screen_stats[1], (unsigned long long)mine);
+    if (n_bad) atomicAdd(&rb.screen_stats[2], (unsigned long long)n_bad);
+    if (n_dead) atomicAdd(&rb.screen_stats[3], (unsigned long long)n_dead);
   }
 }
 
@@ -478,7 +506,7 @@ int launch_render_front(const RenderCfg& cfg, const RenderBuffers& rb, const flo
 
 int launch_render_promote(const RenderCfg& cfg, const RenderBuffers& rb, const int* d_active, int B,
                           hipStream_t stream) {
-  dim3 grid((cfg.R + 15) / 16, cfg.F, B);
+  dim3 grid((cfg.R + 16 * PROMOTE_RPW - 1) / (16 * PROMOTE_RPW), cfg.F, B);
   hipLaunchKernelGGL(k_promote, grid, dim3(1024), 0, stream, cfg, rb, d_active);
   HM_CHECK_HIP(hipGetLastError());
   return 0;

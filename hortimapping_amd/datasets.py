@@ -147,23 +147,7 @@ class ShapeCompletionDataset:
         item["fid"] = fid
         return item
 
-    def prefetch(self, workers: int = 8):
-        """Start reading every item on a pool of reader threads (PNG / npy / txt decode and the depth filters are numpy /
-        PIL work that drops the GIL); `__iter__` then hands the items out in the usual order as they arrive.  The entry
-        point calls this BEFORE its heavy imports and the decoder build, which hides the read behind them."""
-        from concurrent.futures import ThreadPoolExecutor
-        self._pool = ThreadPoolExecutor(max_workers=int(workers), thread_name_prefix="hm-reader")
-        self._futures = [self._pool.submit(self.__getitem__, i) for i in range(len(self))]
-        return self
-
     def __iter__(self):
-        futures = getattr(self, "_futures", None)
-        if futures is not None:
-            self._futures = None
-            for f in futures:
-                yield f.result()
-            self._pool.shutdown(wait=False)
-            return
         for i in range(len(self)):
             yield self[i]
 

@@ -82,16 +82,13 @@ class StageTimer:
         self._t = time.perf_counter()
         self._t0 = self._t
 
-    def lap(self, name, since=None):
-        """`since`: a time.perf_counter() stamp taken before this timer existed (the script's imports)."""
+    def lap(self, name):
         if not self.path:
             return
         import time
         if torch.cuda.is_available():
             torch.cuda.synchronize()
         now = time.perf_counter()
-        if since is not None:
-            self._t = self._t0 = since
         self.stages[name] = self.stages.get(name, 0.0) + (now - self._t)
         self._t = now
 

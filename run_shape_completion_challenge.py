@@ -14,10 +14,16 @@ import time
 
 import click
 import numpy as np
+import torch
 import yaml
 from numpy.linalg import inv
 
-from hortimapping_amd import datasets as DS          # numpy / PIL only: the readers start before torch is imported
+from hortimapping_amd import data_prep as DP, datasets as DS
+from hortimapping_amd.mesher import MeshExtractor, write_ply
+from hortimapping_amd.metrics import ChamferDistance, PrecisionRecall
+from hortimapping_amd.optimizer import Instance, Optimizer
+from hortimapping_amd.utils import StageTimer
+from test_wild_completion import load_decoder
 
 
 @click.command()
@@ -27,24 +33,10 @@ from hortimapping_amd import datasets as DS          # numpy / PIL only: the rea
 @click.option("--dump-jobs", type=str, default="", hidden=True,
               help="(tests) torch.save the prepared per-instance inputs and the raw optimiser results here")
 def main(config, dump_jobs):
-    t_start = time.perf_counter()
-    cfg = yaml.safe_load(open(config))
-    # the split is read by a pool of reader threads while this thread imports torch, loads the library and builds the
-    # decoder (round 6: the read was the largest stage of the script, 1.07 s of 3.3 s for 64 fruits, fruit by fruit)
-    data = DS.ShapeCompletionDataset(cfg["data_dir"], cfg["split"])
-    if os.environ.get("HM_PREFETCH", "1") != "0":
-        data.prefetch()
-    import torch
-    from hortimapping_amd import data_prep as DP
-    from hortimapping_amd.mesher import MeshExtractor, write_ply
-    from hortimapping_amd.metrics import ChamferDistance, PrecisionRecall
-    from hortimapping_amd.optimizer import Instance, Optimizer
-    from hortimapping_amd.utils import StageTimer
-    from test_wild_completion import load_decoder
     np.random.seed(42)
     torch.manual_seed(42)
     timer = StageTimer()                                                    # off unless HM_STAGE_TIMES names a file
-    timer.lap("imports (torch, library) beside the dataset readers", since=t_start)
+    cfg = yaml.safe_load(open(config))
     dtype = torch.float32
     decoder, init_latent, _ = load_decoder(cfg)
     code_len = init_latent.shape[0]
@@ -59,6 +51,7 @@ def main(config, dump_jobs):
     opt = Optimizer(cfg, decoder, mesh_extractor, None)
     cd_metric = ChamferDistance(backend="gpu")                            # 1,000,000-point clouds: hm_nn_distance
     pr_metric = PrecisionRecall(min_t=0.001, max_t=0.01, num=100, backend="gpu")          # :83
+    data = DS.ShapeCompletionDataset(cfg["data_dir"], cfg["split"])
     result_folder = os.path.join(cfg["data_dir"], "results", cfg["run_name"], cfg["split"])
     os.makedirs(result_folder, exist_ok=True)
     gt_valid = cfg["split"] != "test"

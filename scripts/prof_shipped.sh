@@ -1,13 +1,13 @@
 #!/bin/bash
-# rocprofv3 kernel stats of the shipped configurations at their real render-block sizes (bench.py --shipped-only), round 4
+# rocprofv3 kernel stats of the shipped configurations at their real render-block sizes (bench.py --shipped-only), round 4; file names carry the round they were last taken in
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 mkdir -p $R/gpurun_out
 for c in configs0_wild_pepper configs2_challenge_pepper configs4_lab_pepper_berry; do
   rm -rf /tmp/prof_$c && mkdir -p /tmp/prof_$c
-  (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$c -o p -- python $R/bench.py --shipped-only $c --groups 1 --steps 3 --warmup 1 > $R/gpurun_out/r05_${c}_bench_under_rocprof.json 2> /tmp/prof_$c.err)
+  (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$c -o p -- python $R/bench.py --shipped-only $c --groups 1 --steps 3 --warmup 1 > $R/gpurun_out/r06_${c}_bench_under_rocprof.json 2> /tmp/prof_$c.err)
   f=$(find /tmp/prof_$c -name "*kernel_stats.csv" | head -1)
-  python - "$f" > $R/gpurun_out/r05_${c}_kernel_stats.txt <<'PY'
+  python - "$f" > $R/gpurun_out/r06_${c}_kernel_stats.txt <<'PY'
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 tot = sum(float(r["TotalDurationNs"]) for r in rows)

@@ -18,19 +18,20 @@ Lewiner tables (`tests/test_gpu_mesher.py`, `oracle/level_set.py`).
 or `synthetic:latent=<L>,seed=<s>[,r0=<r>]` for the analytic decoder (the reference tree ships no weights)."""
 import os
 
-import time
-
 import click
 import numpy as np
+import torch
 import yaml
 from numpy.linalg import det, inv
 
-from hortimapping_amd import datasets as DS, synthetic as S     # numpy / PIL only: the frame reader starts before torch is imported
+from hortimapping_amd import data_prep as DP, datasets as DS, synthetic as S
+from hortimapping_amd.decoder import DecoderWeights, config_decoder, load_latent_vectors
+from hortimapping_amd.mesher import MeshExtractor, read_ply, write_ply
+from hortimapping_amd.optimizer import Instance, Optimizer, STATUS_INVALID
+from hortimapping_amd.utils import StageTimer
 
 
 def load_decoder(cfg):
-    import torch
-    from hortimapping_amd.decoder import DecoderWeights, config_decoder, load_latent_vectors
     d = cfg["deepsdf_dir"]
     if isinstance(d, str) and d.startswith("synthetic:"):
         kv = dict(x.split("=") for x in d[len("synthetic:"):].split(","))
@@ -49,22 +50,10 @@ def load_decoder(cfg):
 @click.option("--dump-jobs", type=str, default="", hidden=True,
               help="(tests) torch.save the prepared per-instance inputs and the raw optimiser results here")
 def main(config, dump_jobs):
-    t_start = time.perf_counter()
-    cfg = yaml.safe_load(open(config))
-    # the frames (id / depth / colour images + poses) are read on a reader thread while this thread imports torch, loads
-    # the library and builds the decoder (PIL decoding drops the GIL)
-    from concurrent.futures import ThreadPoolExecutor
-    reader = ThreadPoolExecutor(max_workers=1, thread_name_prefix="hm-reader")
-    frames_future = reader.submit(DS.load_bup20_frames, cfg)
-    import torch
-    from hortimapping_amd import data_prep as DP
-    from hortimapping_amd.mesher import MeshExtractor, read_ply, write_ply
-    from hortimapping_amd.optimizer import Instance, Optimizer, STATUS_INVALID
-    from hortimapping_amd.utils import StageTimer
     np.random.seed(42)                                                  # set_random_seed(42), utils.py:638-641
     torch.manual_seed(42)
     timer = StageTimer()                                                # off unless HM_STAGE_TIMES names a file
-    timer.lap("imports (torch, library) beside the frame reader", since=t_start)
+    cfg = yaml.safe_load(open(config))
     dtype = torch.float32
     decoder, init_latent, _ = load_decoder(cfg)
     code_len = init_latent.shape[0]
@@ -80,8 +69,7 @@ def main(config, dump_jobs):
     voxels_dim = int(2 * object_radius_max_m * 1e3 / float(cfg["vis"]["mc_res_mm"]))
     K, _, img_size = DS.load_cam_info(cfg["cam_info_path"])
     invK = inv(K)
-    frames = frames_future.result()
-    reader.shutdown(wait=False)
+    frames = DS.load_bup20_frames(cfg)
     print("Loaded %d frames, image size %s" % (len(frames["id"]), img_size))
 
     mesh_extractor = MeshExtractor(decoder, code_len=code_len, voxels_dim=voxels_dim, cube_radius=object_radius_max_m)
