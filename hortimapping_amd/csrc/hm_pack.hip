@@ -42,8 +42,25 @@ struct Blob {
   }
 };
 
+// A stage's operand matrix, materialised ONCE from its accessor (512 rows x `cols`, zero outside the accessor's range): the
+// packers below read it three to five times per element, and through a std::function that was most of the 0.4 s a decoder
+// handle took to create (round 6; the packed bytes are the same).
+struct Dense {
+  std::vector<float> v;
+  int cols = 0;
+  float operator()(int r, int c) const { return c < cols ? v[(size_t)r * cols + c] : 0.f; }
+};
+Dense materialise(const std::function<float(int, int)>& A, int mb_lo, int mb_hi, int kmax, int cols) {
+  Dense d;
+  d.cols = cols;
+  d.v.assign((size_t)HID * cols, 0.f);
+  for (int r = mb_lo * 32; r < mb_hi * 32; ++r)
+    for (int c = 0; c < kmax; ++c) d.v[(size_t)r * cols + c] = A(r, c);
+  return d;
+}
+
 // A(r, c) accessor -> packed [n_mb][n_kg][64][4]
-size_t pack_stage(Blob& blob, int mb_lo, int mb_hi, int n_kg, const std::function<float(int, int)>& A) {
+size_t pack_stage(Blob& blob, int mb_lo, int mb_hi, int n_kg, const Dense& A) {
   const int n_mb = mb_hi - mb_lo;
   size_t off = blob.alloc((size_t)n_mb * n_kg * 256);
   for (int mbi = 0; mbi < n_mb; ++mbi)
@@ -61,7 +78,7 @@ size_t pack_stage(Blob& blob, int mb_lo, int mb_hi, int n_kg, const std::functio
 //   hi = fp16(A * 2^s),  lo = fp16(A * 2^s - hi);   the kernel forms  hi*Xh + (hi*2^-11)*(Xl*2^11) + lo*Xh.
 // Layout [mb][k16][hi|lo][lane][8]: lane l holds row l&31, k = 16*step + 8*(l>>5) + j.
 size_t pack_stage_h(std::vector<uint16_t>& blob, int mb_lo, int mb_hi, int n_k16, int mb_stride,
-                    const std::function<float(int, int)>& A, float* unscale) {
+                    const Dense& A, float* unscale) {
   const int n_mb = mb_hi - mb_lo;
   float mx = 0.f;
   for (int r = mb_lo * 32; r < mb_hi * 32; ++r)
@@ -107,9 +124,10 @@ size_t pack_stream_p(std::vector<uint16_t>& blob, const std::function<float(int,
   blob.resize(off + (size_t)NWAVE * T * 2 * 64 * 8, 0);
   int t0 = 0;
   for (int s = 0; s < NSTAGE; ++s) {
+    const Dense As = materialise(A[s], lo[s], hi[s], kmax[s], kmax[s]);
     float mx = 0.f;
     for (int r = lo[s] * 32; r < hi[s] * 32; ++r)
-      for (int c = 0; c < kmax[s]; ++c) mx = fmaxf(mx, fabsf(A[s](r, c)));
+      for (int c = 0; c < kmax[s]; ++c) mx = fmaxf(mx, fabsf(As(r, c)));
     int shift = 12;
     while (shift > -12 && ldexpf(mx, shift) >= 32768.f) --shift;
     unscale[s] = ldexpf(1.f, -shift);
@@ -123,7 +141,7 @@ size_t pack_stream_p(std::vector<uint16_t>& blob, const std::function<float(int,
             for (int e = 0; e < 8; ++e) {
               const int r = mb * 32 + (lane & 31);
               const int c = 16 * t + 8 * (e >> 2) + 4 * (lane >> 5) + (e & 3);
-              const float v = c < kmax[s] ? ldexpf(A[s](r, c), shift) : 0.f;
+              const float v = c < kmax[s] ? ldexpf(As(r, c), shift) : 0.f;
               const __half hv = __float2half_rn(v);
               blob[off + ((((size_t)w * T + t0 + t) * 2 + rb) * 64 + lane) * 8 + e] = *reinterpret_cast<const uint16_t*>(&hv);
             }
@@ -163,14 +181,14 @@ extern "C" int hm_decoder_create(int latent_dim, const float* const* W, const fl
     Afun[s] = A; s_kmax[s] = n_kg * 8; s_lo[s] = lo; s_hi[s] = hi;
     st[s].n_kg = n_kg; st[s].mb_lo = lo; st[s].mb_hi = hi; st[s].epi = epi; st[s].layer = layer;
     st[s].inst_bias = inst_bias;
-    pend[s].wp = pack_stage(blob, lo, hi, n_kg, A);
-    {   // same stage for the f16x3 kernel: K padded to a multiple of 16 with zero columns
-      const int kmax = n_kg * 8;
-      const int n_k16 = (kmax + 15) / 16;
-      auto Ap = [&](int r, int c) { return c < kmax ? A(r, c) : 0.f; };
+    const int kmax = n_kg * 8;
+    const int n_k16 = (kmax + 15) / 16;
+    const Dense Ad = materialise(A, lo, hi, kmax, n_k16 * 16);     // K padded to a multiple of 16 with zero columns
+    pend[s].wp = pack_stage(blob, lo, hi, n_kg, Ad);
+    {   // same stage for the f16x3 kernel
       sth[s].n_k16 = n_k16;
       sth[s].mb_stride = n_k16 * 128;
-      hoff[s] = pack_stage_h(hblob, lo, hi, n_k16, sth[s].mb_stride, Ap, &sth[s].unscale);
+      hoff[s] = pack_stage_h(hblob, lo, hi, n_k16, sth[s].mb_stride, Ad, &sth[s].unscale);
     }
     pend[s].has_bias = 0;
     if (bfun) {
@@ -308,10 +326,12 @@ extern "C" int hm_decoder_create_arch(const hm_decoder_arch* arch, const float* 
     const float* Wl = W[l];
     const std::function<float(int, int)> Af = [&](int r, int c) { return (r < od && c < in) ? Wl[(size_t)r * in + c] : 0.f; };
     const std::function<float(int, int)> Ab = [&](int r, int c) { return (r < in && c < od) ? Wl[(size_t)c * in + r] : 0.f; };
-    o_wf[l] = pack_stage(blob, 0, (od + 31) / 32, (in + 7) / 8, Af);
-    o_wb[l] = pack_stage(blob, 0, (in + 31) / 32, (od + 7) / 8, Ab);
-    h_wf[l] = pack_stage_h(hblob, 0, (od + 31) / 32, (in + 15) / 16, ((in + 15) / 16) * 128, Af, &usf[l]);
-    h_wb[l] = pack_stage_h(hblob, 0, (in + 31) / 32, (od + 15) / 16, ((od + 15) / 16) * 128, Ab, &usb[l]);
+    const Dense Afd = materialise(Af, 0, (od + 31) / 32, ((in + 15) / 16) * 16, ((in + 15) / 16) * 16);
+    const Dense Abd = materialise(Ab, 0, (in + 31) / 32, ((od + 15) / 16) * 16, ((od + 15) / 16) * 16);
+    o_wf[l] = pack_stage(blob, 0, (od + 31) / 32, (in + 7) / 8, Afd);
+    o_wb[l] = pack_stage(blob, 0, (in + 31) / 32, (od + 7) / 8, Abd);
+    h_wf[l] = pack_stage_h(hblob, 0, (od + 31) / 32, (in + 15) / 16, ((in + 15) / 16) * 128, Afd, &usf[l]);
+    h_wb[l] = pack_stage_h(hblob, 0, (in + 31) / 32, (od + 15) / 16, ((od + 15) / 16) * 128, Abd, &usb[l]);
     o_b[l] = blob.alloc(HM_ANY_MAX_WIDTH);
     for (int f = 0; f < od; ++f) blob.host[o_b[l] + f] = bias[l][f];
     o_g[l] = o_be[l] = 0;
