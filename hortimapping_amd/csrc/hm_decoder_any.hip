@@ -47,6 +47,7 @@ struct AnyArgs {
   float* J;            // [B][n_stride][ldJ]
   float* ln_slab;      // [ANY_GRID][n_ln][SLAB] (unused without LayerNorm layers)
   float* gi_slab;      // [ANY_GRID][MAX_L][64]: d sdf / d z of the tile in flight, query-minor
+  unsigned long long* mk_slab;   // [ANY_GRID][HM_ANY_MAX_LIN][512]: ReLU masks of the tile in flight, one word per thread and layer
   int n_stride, B, ldJ, pose_dim, n_tiles;
 };
 
@@ -119,7 +120,11 @@ __global__ __launch_bounds__(512, 2) void k_decoder_any(const AnyArgs a) {
     if (MODE == 1 && tid < 3 * 64) gxs[tid] = 0.f;
     bool gi_first = true;
 
-    unsigned long long mk[HM_ANY_MAX_LIN];
+    // ReLU masks (64 bits per thread and layer): through the launch's scratch block -- one coalesced 8-byte store per layer in
+    // the forward pass, one load per layer in the backward pass -- instead of a 16-entry array indexed by the layer loop's
+    // counter (32 registers, or scratch memory: what the backward instantiations spilled; round 6).  Forward-only launches
+    // (MODE 0) have no block and store nothing.
+    unsigned long long* const mkp = MODE == 1 ? a.mk_slab + ((size_t)blockIdx.x * HM_ANY_MAX_LIN) * 512 + tid : nullptr;
     f32x16 acc[2][2];
     float yA = 0.f, yB = 0.f, tA = 0.f, tB = 0.f;   // sdf / inner tanh of queries qa and qa + 32 (wave 0, hi = 0)
     int ln_i = 0;
@@ -222,7 +227,7 @@ __global__ __launch_bounds__(512, 2) void k_decoder_any(const AnyArgs a) {
           }
         }
       }
-      mk[l] = bits;
+      if (MODE == 1) mkp[(size_t)l * 512] = bits;
       if (LN && ly.ln) ++ln_i;
       const int cat = a.dec.lay[l + 1].cat;
       if (cat != 0) {    // :87-90 x = cat[x, input] (latent_in) or cat[x, xyz] (xyz_in_all)
@@ -284,7 +289,7 @@ __global__ __launch_bounds__(512, 2) void k_decoder_any(const AnyArgs a) {
       if (l == 0) break;
       // gradient w.r.t. the pre-activation of layer l - 1: ReLU mask, then LayerNorm backward
       const AnyLayer& lp = a.dec.lay[l - 1];
-      const unsigned long long bits = mk[l - 1];
+      const unsigned long long bits = mkp[(size_t)(l - 1) * 512];
 #pragma unroll
       for (int sl = 0; sl < 2; ++sl)
 #pragma unroll
@@ -445,7 +450,11 @@ __global__ __launch_bounds__(512, 2) void k_decoder_any_h(const AnyArgs a) {
     if (MODE == 1 && tid < 3 * 64) gxs[tid] = 0.f;
     bool gi_first = true;
 
-    unsigned long long mk[HM_ANY_MAX_LIN];
+    // ReLU masks (64 bits per thread and layer): through the launch's scratch block -- one coalesced 8-byte store per layer in
+    // the forward pass, one load per layer in the backward pass -- instead of a 16-entry array indexed by the layer loop's
+    // counter (32 registers, or scratch memory: what the backward instantiations spilled; round 6).  Forward-only launches
+    // (MODE 0) have no block and store nothing.
+    unsigned long long* const mkp = MODE == 1 ? a.mk_slab + ((size_t)blockIdx.x * HM_ANY_MAX_LIN) * 512 + tid : nullptr;
     f32x16 acc[2][2];
     float yA = 0.f, yB = 0.f, tA = 0.f, tB = 0.f;   // sdf / inner tanh of queries qa and qa + 32 (wave 0, hi = 0)
     int ln_i = 0;
@@ -553,7 +562,7 @@ __global__ __launch_bounds__(512, 2) void k_decoder_any_h(const AnyArgs a) {
           }
         }
       }
-      mk[l] = bits;
+      if (MODE == 1) mkp[(size_t)l * 512] = bits;
       if (LN && ly.ln) ++ln_i;
       const int cat = a.dec.lay[l + 1].cat;
       if (cat != 0) {    // :87-90 x = cat[x, input] (latent_in) or cat[x, xyz] (xyz_in_all)
@@ -624,7 +633,7 @@ __global__ __launch_bounds__(512, 2) void k_decoder_any_h(const AnyArgs a) {
       if (l == 0) break;
       // gradient w.r.t. the pre-activation of layer l - 1: ReLU mask, then LayerNorm backward
       const AnyLayer& lp = a.dec.lay[l - 1];
-      const unsigned long long bits = mk[l - 1];
+      const unsigned long long bits = mkp[(size_t)(l - 1) * 512];
 #pragma unroll
       for (int sl = 0; sl < 2; ++sl)
 #pragma unroll
@@ -747,8 +756,8 @@ int launch_decoder_any(const hm_decoder_s* dec, int B, const float* d_pts, const
   a.n_tiles = B * (n_stride / TQ);
   if (a.n_tiles == 0) return 0;
   const int grid = a.n_tiles < ANY_GRID ? a.n_tiles : ANY_GRID;
-  // The per-workgroup scratch of the backward pass (LayerNorm saves + the d sdf / d z block) belongs to the LAUNCH: it is
-  // allocated and released on the launch's stream.  (Up to round 5 it was one block per decoder handle, indexed by
+  // The per-workgroup scratch of the backward pass (LayerNorm saves, the d sdf / d z block, the ReLU masks) belongs to the
+  // launch's STREAM (hm_internal.h: scratch_get).  (Up to round 5 it was one block per decoder handle, indexed by
   // blockIdx.x only: the two instance groups of hm_optimize_batch, two workspaces or two host threads on one handle
   // then read-modify-wrote each other's slots.)  The forward-only kernels do not touch it.
   if (dec->precision != 0 && dec->precision != 1) {
@@ -757,10 +766,13 @@ int launch_decoder_any(const hm_decoder_s* dec, int B, const float* d_pts, const
   }
   void* slab = nullptr;
   if (mode != 0) {
-    HM_CHECK_HIP(hipMallocAsync(&slab, (size_t)grid * ((size_t)dec->any.n_ln * SLAB + MAX_L * 64) * sizeof(float), stream));
+    const int rc = scratch_get(&slab, (size_t)grid * (((size_t)dec->any.n_ln * SLAB + MAX_L * 64) * sizeof(float) +
+                                                        (size_t)HM_ANY_MAX_LIN * 512 * sizeof(unsigned long long)), stream);
+    if (rc) return rc;
   }
   a.ln_slab = static_cast<float*>(slab);
   a.gi_slab = a.ln_slab + (size_t)grid * dec->any.n_ln * SLAB;
+  a.mk_slab = reinterpret_cast<unsigned long long*>(a.gi_slab + (size_t)grid * MAX_L * 64);
   const bool ln = dec->any.n_ln > 0;      // tables without LayerNorm run kernels compiled without its code paths
 #define HM_ANY_LAUNCH(K, M)                                                                     \
   do {                                                                                          \
@@ -773,10 +785,7 @@ int launch_decoder_any(const hm_decoder_s* dec, int B, const float* d_pts, const
     if (mode == 0) HM_ANY_LAUNCH(k_decoder_any, 0); else HM_ANY_LAUNCH(k_decoder_any, 1);
   }
 #undef HM_ANY_LAUNCH
-  const hipError_t le = hipGetLastError();
-  const hipError_t fe = slab != nullptr ? hipFreeAsync(slab, stream) : hipSuccess;
-  HM_CHECK_HIP(le);
-  HM_CHECK_HIP(fe);
+  HM_CHECK_HIP(hipGetLastError());
   return 0;
 }
 

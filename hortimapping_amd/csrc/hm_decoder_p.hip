@@ -617,11 +617,10 @@ int launch_decoder_p(const hm_decoder_s* dec, int B, const float* d_pts, const i
     return 0;
   }
   // forward + backward = two launches: forward with the ReLU masks written to a scratch block (64 KiB per workgroup), then
-  // the backward-only kernel.  The block is STREAM-ORDERED (allocated and released on the launch's stream): concurrent
-  // launches on one decoder handle -- instance groups, several workspaces, host threads -- never share it, and nothing
-  // outlives the pair
+  // the backward-only kernel.  The block belongs to the STREAM (hm_internal.h: scratch_get): concurrent launches on one
+  // decoder handle -- instance groups, several workspaces, host threads -- are on different streams and never share it
   void* scr = nullptr;
-  HM_CHECK_HIP(hipMallocAsync(&scr, (size_t)grid * 8 * 512 * sizeof(u32x4), stream));
+  { const int rc = scratch_get(&scr, (size_t)grid * 8 * 512 * sizeof(u32x4), stream); if (rc) return rc; }
   a.mscr = static_cast<u32x4*>(scr);
   if (tag == 0) {
     hipLaunchKernelGGL((k_decoder_p<2, 0>), dim3(grid), dim3(512), 0, stream, a);
@@ -630,10 +629,7 @@ int launch_decoder_p(const hm_decoder_s* dec, int B, const float* d_pts, const i
     hipLaunchKernelGGL((k_decoder_p<2, 1>), dim3(grid), dim3(512), 0, stream, a);
     hipLaunchKernelGGL((k_decoder_p<3, 1>), dim3(grid), dim3(512), 0, stream, a);
   }
-  const hipError_t le = hipGetLastError();
-  const hipError_t fe = hipFreeAsync(scr, stream);
-  HM_CHECK_HIP(le);
-  HM_CHECK_HIP(fe);
+  HM_CHECK_HIP(hipGetLastError());
   return 0;
 }
 

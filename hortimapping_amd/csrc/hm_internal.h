@@ -141,6 +141,16 @@ int launch_decoder_h_bwd(const hm_decoder_s* dec, int B, const int* d_active, co
                          const int* d_srcG, const float* d_yR, const void* d_maskR, int nR_stride,
                          hipStream_t stream);
 
+// Scratch of a launch (K1p's ReLU-mask block, the any-architecture kernels' backward slabs): ONE block per (device, stream), kept by
+// the library and grown on demand (hm_pack.hip).  Launches on one stream run one after the other, so they can share the block;
+// launches on different streams -- the instance groups of hm_optimize_batch, concurrent calls, host threads -- never do (the
+// round-5 per-decoder block, indexed by blockIdx.x only, was shared by concurrent groups: ADVICE r05).  Round 6 first used a
+// stream-ordered allocation per launch (hipMallocAsync / hipFreeAsync): correct, but the pool hands a block freed on one stream to
+// the next allocation on ANOTHER stream behind an internal dependency, which tied the two instance groups of a call together
+// (whole any-architecture jobs 129 -> 119 instances/s) and, with the default release threshold, re-allocated after every
+// synchronisation (40-80 ms outliers).  No allocation call is left on the launch path once a stream has seen its largest launch.
+int scratch_get(void** p, size_t bytes, hipStream_t stream);
+
 int launch_decoder_p(const hm_decoder_s* dec, int B, const float* d_pts, const int* d_nq, const int* d_active,
                      int n_stride, const float* d_c0, const float* d_c4, float* d_y, float* d_J, int ldJ,
                      int pose_dim, int mode, hipStream_t stream, int tag);

@@ -10,6 +10,8 @@
 #include <string.h>
 
 #include <functional>
+#include <map>
+#include <mutex>
 #include <vector>
 
 #include <hip/hip_fp16.h>
@@ -30,6 +32,35 @@ extern "C" void hm_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* hm_last_error(void) { return g_err; }
+
+namespace hm {
+int scratch_get(void** p, size_t bytes, hipStream_t stream) {
+  struct Block { void* ptr; size_t bytes; };
+  static std::mutex mu;
+  static std::map<std::pair<int, hipStream_t>, Block> blocks;
+  int dev = 0;
+  HM_CHECK_HIP(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lk(mu);
+  Block& b = blocks[std::make_pair(dev, stream)];
+  if (b.bytes < bytes) {
+    // grow (rare: a stream's first launch, or a larger launch than any before; geometric, so a few times per stream at
+    // most): launches already enqueued on this stream may still use the old block -> wait for them, then release it
+    size_t want = bytes > b.bytes + b.bytes / 2 ? bytes : b.bytes + b.bytes / 2;
+    want = (want + (size_t(1) << 20) - 1) & ~((size_t(1) << 20) - 1);
+    if (b.ptr != nullptr) {
+      HM_CHECK_HIP(hipStreamSynchronize(stream));
+      HM_CHECK_HIP(hipFree(b.ptr));
+    }
+    b.ptr = nullptr; b.bytes = 0;
+    void* q = nullptr;
+    hipError_t e = hipMalloc(&q, want);
+    if (e != hipSuccess) { hm_set_error("hipMalloc(%zu) of a launch scratch block failed: %s", want, hipGetErrorString(e)); return -2; }
+    b.ptr = q; b.bytes = want;
+  }
+  *p = b.ptr;
+  return 0;
+}
+}  // namespace hm
 
 namespace {
 
