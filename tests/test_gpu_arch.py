@@ -341,7 +341,7 @@ def test_fuzz_random_layer_tables_vs_fp64_oracle(arith):
 def test_instance_groups_share_one_generic_decoder_without_sharing_scratch(table, arith):
     """the any-architecture kernels kept their backward scratch (d sdf / d z block, LayerNorm saves) in ONE
     per-decoder allocation indexed by blockIdx.x, so the two instance groups hm_optimize_batch runs on internal streams
-    (B >= 16) read-modify-wrote each other's slots.  The scratch now belongs to the launch (stream-ordered allocation): 20
+    (B >= 16) read-modify-wrote each other's slots.  The scratch now belongs to the launch's stream (one block per stream, hm_pack.hip: scratch_get): 20
     instances, several tiles per launch, groups = 1 / 2 / 4 must give the same bits -- on a weight-normed table and on a
     LayerNorm table."""
     from hortimapping_amd import optimizer as HO, synthetic as S, workloads as W
