@@ -214,7 +214,12 @@ int hm_workspace_counters_read(hm_workspace_t ws, long long* out5, void* stream)
  * non-blocking streams (a process-wide pool of at most four per device, shared by all workspaces so that the number of
  * streams -- and with it their mapping onto the runtime's hardware queues -- does not grow with the number of workspaces),
  * forked from and joined back into `stream` by events; the caller's stream sees one fork and one join.  A workspace must
- * not be used by two calls at the same time; calls on DIFFERENT workspaces may overlap (they take turns on the pool).
+ * not be used by two calls at the same time; calls on DIFFERENT workspaces -- from different host threads, each with its
+ * own caller stream; the decoder handle may be shared -- may overlap: a call leases its group streams from the pool for its
+ * duration, so concurrent calls get disjoint streams (a call that finds fewer idle streams than it wants groups runs with
+ * the groups it can get, down to one group on the caller's stream; results never depend on the grouping).  Two host
+ * threads must not enqueue on the SAME caller stream at the same time (the library keeps one launch-scratch block per
+ * stream).  `stream` may be a non-blocking stream.
  *
  * Host behaviour -- this call is NOT always a pure enqueue:
  *   - every epsilon_* == 0 (forced iterations): all cfg->max_iter iterations are enqueued and the call returns without
