@@ -374,7 +374,7 @@ int begin_call(hm_workspace_s* ws, int joint) {
       ws->d_maskR = nullptr; ws->maskR_bytes = 0; return -2; }
     ws->rb.maskR = ws->d_maskR;
   }
-  if (joint && fused_path(ws) && ws->screen_mode == 2 && ws->d_sdfFull == nullptr) {
+  if (joint && fused_path(ws) && ws->screen_mode >= 2 && ws->d_sdfFull == nullptr) {
     ws->sdfFull_bytes = (size_t)ws->lim.max_batch * ws->nR_stride * sizeof(float);
     hipError_t e = hipMalloc(reinterpret_cast<void**>(&ws->d_sdfFull), ws->sdfFull_bytes);
     if (e != hipSuccess) {
@@ -587,7 +587,7 @@ extern "C" size_t hm_workspace_bytes(hm_workspace_s* w) { return w ? w->blob_byt
 
 extern "C" int hm_workspace_set_screening(hm_workspace_s* w, int mode, float eps) {
   if (w == nullptr) { hm_set_error("null workspace"); return -1; }
-  if (mode < 0 || mode > 2) { hm_set_error("screening mode must be 0 (off), 1 (on) or 2 (on + verify)"); return -1; }
+  if (mode < 0 || mode > 3) { hm_set_error("screening mode must be 0 (off), 1 (on), 2 (on + verify) or 3 (on + verify the first iteration)"); return -1; }
   if (eps < 0.f) { hm_set_error("screening margin must be >= 0 (0 selects the default)"); return -1; }
   w->screen_mode = mode;
   w->screen_eps = eps > 0.f ? eps : HM_SCREEN_EPS_DEFAULT;
@@ -627,6 +627,8 @@ struct OptRun {
   int mode, P;
   RenderCfg rcfg;
   RenderBuffers rb;
+  int screen_call;           // the call's screening mode (3 = verify in iteration 0 only: rcfg.screen is set per iteration)
+  unsigned long long* stats; // this group's screening-statistics words
   int n_checks, check_every;
   bool done;
 };
@@ -668,7 +670,11 @@ int opt_begin(OptRun& r, const hm_opt_cfg* cfg) {
   r.rcfg = make_render_cfg(ws, cfg);
   r.rb = ws->rb;
   if (r.mode == 0) { bind_inputs(r.rb, bt); r.rb.status = bt->d_status; }
-  // screening statistics cost three atomics per ray: only with the work counters on, or in verify mode
+  // screening statistics cost three atomics per ray: only with the work counters on, or in verify mode (mode 3: the
+  // first iteration verifies -- opt_iteration switches both per iteration)
+  r.screen_call = r.rcfg.screen;
+  r.stats = r.rb.screen_stats;
+  if (r.screen_call == 3) r.rcfg.screen = 2;
   if (!(r.owner->count_on || r.rcfg.screen == 2)) r.rb.screen_stats = nullptr;
   // Early stop of the LAUNCH loop.  Finished instances are frozen on the device (`active` flags), so results never depend
   // on this; but a batch whose instances have all converged by iteration 7 of max_iter 50 would still be sent 43 x 13
@@ -692,6 +698,10 @@ int opt_iteration(OptRun& r, const hm_opt_cfg* cfg, int it, hipEvent_t after_mai
   hm_workspace_s* ws = r.ws;
   const hm_batch* bt = &r.bt;
   const hm_debug* dbg = r.dbg;
+  if (r.screen_call == 3) {        // verify the screened decisions in the first iteration, plain screening afterwards
+    r.rcfg.screen = it == 0 ? 2 : 1;
+    r.rb.screen_stats = (r.owner->count_on || it == 0) ? r.stats : nullptr;
+  }
   const RenderCfg& rcfg = r.rcfg;
   RenderBuffers& rb = r.rb;
   hipStream_t st = r.st;

@@ -165,7 +165,8 @@ class Workspace:
         return self
 
     def set_screening(self, mode: int, eps: float = 0.0):
-        """Linear-occupancy screening of the ray samples (include/hortimapping_amd.h): 0 off, 1 on (default), 2 on + verify."""
+        """Linear-occupancy screening of the ray samples (include/hortimapping_amd.h): 0 off, 1 on (default), 2 on + verify,
+        3 on + verify the first iteration of each call."""
         lib = _lib.lib()
         lib.hm_workspace_set_screening.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_float]
         _lib.check(lib.hm_workspace_set_screening(self.handle, int(mode), float(eps)), "hm_workspace_set_screening")
@@ -402,15 +403,16 @@ def optimize_batch(dec: DecoderWeights, opt: dict, instances: Sequence[Instance]
         cache["ws"] = workspace
     # Linear-occupancy screening (include/hortimapping_amd.h): exact as long as the one-pass fp16 sdf stays within the
     # margin of the f16x3 value -- measured on four decoders, not a property of every decoder a user may train.  So the
-    # FIRST screened call on a decoder handle runs in verify mode (the exact forward over every sample rides along and
-    # contradicted decisions are counted): no violation -> the handle is trusted from then on; any violation -> this call
-    # is repeated from its initial state without screening and the handle never screens again.
+    # FIRST screened call on a decoder handle verifies its first iteration (mode 3: the exact forward over every sample
+    # rides along there and contradicted decisions are counted; verifying the whole call doubled the optimisation time of
+    # a one-call process such as run_shape_completion_challenge.py): no violation -> the handle is trusted from then on;
+    # any violation -> this call is repeated from its initial state without screening and the handle never screens again.
     screened = (not shape_only and not cfg.log_sdf_occ and cfg.min_grad_thre >= 0 and not dec.generic
                 and dec.precision in ("f16x3", "f16x3f_f16b"))
     state = getattr(dec, "_screening", None) if screened else None
     if screened and state is None:
         init = (pb.latent.clone(), pb.T_ow.clone())
-        workspace.set_screening(2)
+        workspace.set_screening(3)
         run_packed(workspace, cfg, pb, 0, debug)
         bad = workspace.screening_stats(reset=True)["violations"]
         dec._screening = "off" if bad else "trusted"

@@ -252,12 +252,14 @@ int hm_workspace_set_groups(hm_workspace_t ws, int groups);
  * certainly-inside sample of their ray (transmittance exactly 0) are skipped as well.  Results are bit-identical to the
  * unscreened path as long as eps bounds |sdf_fp16 - sdf_f16x3| (default 1e-3 m: DESIGN.md section 4 has the measurement).
  *   mode 0 off, 1 on (default; ignored for logistic occupancy and for precisions 0 / 3), 2 on + VERIFY: the exact forward
- *   also runs over every sample and each screened-far decision is checked against it; eps <= 0 = default.
+ *   also runs over every sample and each screened-far decision is checked against it; 3 = verify in the FIRST iteration
+ *   of each call only (one verified pass per call at 1/max_iter of mode 2's cost); eps <= 0 = default.
  * THE GUARANTEE IS CONDITIONAL: it holds for decoders whose one-pass fp16 error stays inside eps (measured on four
  * decoders; not a property of every network a user may train), and the pass is skipped unless min_grad_thre >= 0 (its
  * dead-sample rule needs `0 > min_grad_thre` to fail as in loss.py:66).  A caller that brings its own decoder should
- * run its first call in mode 2 and read `violations`: 0 -> mode 1 is exact for this decoder; otherwise switch to mode 0
- * (or a larger eps) and repeat the call.  The Python optimize_batch / drop-in Optimizer do this once per decoder handle.
+ * run its first call in mode 2 (or 3) and read `violations`: 0 -> mode 1 is exact for this decoder; otherwise switch to mode 0
+ * (or a larger eps) and repeat the call.  The Python optimize_batch / drop-in Optimizer do this once per decoder handle
+ * (mode 3: the first iteration of the handle's first screened call).
  * hm_workspace_screening_stats (after enabling hm_workspace_counters, or in mode 2): out4 = {ball-valid samples of valid
  * frames screened, promoted to the exact forward, violations found by mode 2 (must be 0), samples skipped behind a
  * certainly-inside one}; synchronises `stream`; reset != 0 zeroes the sums afterwards (out4 may be NULL). */

@@ -173,7 +173,15 @@ def test_shape_completion_challenge_cli_parity(synthetic_data):
         m = read_ply(os.path.join(res_dir, j["name"] + ".ply"))
         m_o = mesher.complete_mesh(torch.from_numpy(z_o), np.linalg.inv(T_o), None)
         assert m.faces.shape[0] > 500 and abs(m.vertices.shape[0] - m_o.vertices.shape[0]) <= 0.02 * m_o.vertices.shape[0]
-        a, b = m.sample_points_uniformly(20000, seed=1), m_o.sample_points_uniformly(20000, seed=1)
-        cd = MX.ChamferDistance(backend="gpu")
-        cd.update(a, b)
-        assert cd.compute() < 2e-4, (j["name"], cd.compute())          # < 0.2 mm (sampling noise of 20k points ~0.1 mm)
+        # Vertex sets against each other (the vertices of a marching-cubes mesh are the level set's crossings of the grid
+        # edges: a latent that differs at the 1e-5 level moves them by micrometres, and where the topology differs in a cell
+        # a vertex has no partner within a fraction of the 4 mm cell).  Round 6: the former check sampled 20,000 points
+        # on each mesh with the SAME seed and asked for a Chamfer distance below 0.2 mm -- which held only while the two face
+        # lists were identical (same random numbers, same faces, same points); one face more or less on either side
+        # decorrelated the two samples, the distance jumped to the sampling noise (~0.3 mm) and the test failed on about
+        # two boxes in nine (the fruit order, and with it each fruit's random draws, follows the box's directory order).
+        from scipy.spatial import cKDTree
+        va, vb = m.vertices.astype(np.float64), m_o.vertices.astype(np.float64)
+        dab, dba = cKDTree(vb).query(va)[0], cKDTree(va).query(vb)[0]
+        assert max(np.median(dab), np.median(dba)) < 1e-4, (j["name"], np.median(dab), np.median(dba))     # typical vertex: < 0.1 mm (measured: micrometres)
+        assert max((dab > 5e-4).mean(), (dba > 5e-4).mean()) < 0.02, j["name"]     # < 2 % of the vertices without a partner within 0.5 mm

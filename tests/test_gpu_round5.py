@@ -160,20 +160,23 @@ def test_linear_occupancy_screening_gives_the_same_bits(case, precision):
     hcfg = HO.opt_cfg_from_dict(opt)
     L = dec.latent_dim
     out = {}
-    for mode in (0, 1, 2):
+    for mode in (0, 1, 2, 3):
         pb = HO.PackedBatch(insts, L, int(opt["render"]["n_frame"]), "cuda")
         ws = HO.Workspace(dec, pb.B, pb.points_stride, pb.F, pb.R, hcfg.n_sample_on_ray).set_screening(mode)
-        if mode == 2:
+        if mode >= 2:
             ws.screening_stats(reset=True)
         HO.run_packed(ws, hcfg, pb, 0)
         torch.cuda.synchronize()
         out[mode] = (pb.latent.cpu(), pb.T_ow.cpu(), pb.iter_count.cpu(), pb.status.cpu())
         if mode == 2:
             st = ws.screening_stats()
+        if mode == 3:                      # round 6: verify in the first iteration only (what the Python host runs once per handle)
+            st3 = ws.screening_stats()
         ws.release()
-    for mode in (1, 2):
+    for mode in (1, 2, 3):
         for a, b in zip(out[0], out[mode]):
             assert torch.equal(a, b), f"screening mode {mode} changed the result"
+    assert st3["violations"] == 0 and 0 < st3["screened"] < st["screened"], (st3, st)     # one iteration's samples, not the call's
     assert torch.isfinite(out[0][0]).all() and int(out[0][2].min()) >= 1
     print(case, precision, st)
     assert st["violations"] == 0
