@@ -233,7 +233,7 @@ def test_full_batch_metric_parity(mode, precision, records):
     lines.append(f"# beyond {K_GROSS:g} x the instance's own band (gross-error tripwire): {gross}")
     os.makedirs("gpurun_out", exist_ok=True)
     tag = "fullsize" if records == "analytic" else records
-    with open(os.path.join("gpurun_out", f"r05_parity_{tag}_{mode}_{precision}.txt"), "w") as f:
+    with open(os.path.join("gpurun_out", f"r06_parity_{tag}_{mode}_{precision}.txt"), "w") as f:
         f.write("\n".join(lines) + "\n")
     print("\n" + "\n".join(lines[-11:]))
     if precision in ("f32", "f16x3"):          # the fp32-class arithmetics are gated; the other modes are reported
@@ -316,7 +316,7 @@ def test_fullsize_against_reference_records(mode, precision, records):
     ratio = float(np.exp(np.mean(np.log((pert_orc.max(axis=0)[:, 0] + tiny) / (pert_ref.max(axis=0)[:, 0] + tiny)))))
     out.append(f"oracle Chamfer noise / reference Chamfer noise over the same {K} perturbations (geometric mean, {nI} instances): {ratio:.2f}")
     os.makedirs("gpurun_out", exist_ok=True)
-    with open(os.path.join("gpurun_out", f"r05_parity_vs_reference_{records}_{mode}_{precision}.txt"), "w") as f:
+    with open(os.path.join("gpurun_out", f"r06_parity_vs_reference_{records}_{mode}_{precision}.txt"), "w") as f:
         f.write("\n".join(out) + "\n")
     print("\n" + "\n".join(out))
     lim = 2.0 if K >= 4 else 3.0
@@ -460,7 +460,7 @@ def test_wellconditioned_free_pose_parity(precision):
     lines.append(f"# largest fraction of the 1e-4 tolerance used: GPU {np.max(dev / tol):.2f} (per metric {np.round((dev / tol).max(axis=0), 2).tolist()}), "
                  f"oracle's own perturbed runs {np.max(noise / tol):.2f}")
     os.makedirs("gpurun_out", exist_ok=True)
-    with open(os.path.join("gpurun_out", f"r05_parity_wellconditioned_free_{precision}.txt"), "w") as f:
+    with open(os.path.join("gpurun_out", f"r06_parity_wellconditioned_free_{precision}.txt"), "w") as f:
         f.write("\n".join(lines) + "\n")
     print("\n" + lines[-1])
     # ... and against the ACTUAL reference loop on the first instances (tests/golden/make_reference_records.py --case wc:
@@ -474,7 +474,7 @@ def test_wellconditioned_free_pose_parity(precision):
     line = (f"# vs the ACTUAL reference on {len(pos)} instances, fraction of the 1e-4 tolerance used: oracle {np.max(d_or / tol[pos]):.2f}, "
             f"GPU {precision} {np.max(d_gr / tol[pos]):.2f}, the reference's own perturbed run {np.max(d_rr / tol[pos]):.2f}")
     print(line)
-    with open(os.path.join("gpurun_out", f"r05_parity_wellconditioned_free_{precision}.txt"), "a") as f:
+    with open(os.path.join("gpurun_out", f"r06_parity_wellconditioned_free_{precision}.txt"), "a") as f:
         f.write(line + "\n")
     assert np.all(d_or <= tol[pos]) and np.all(d_rr <= tol[pos])     # oracle == reference, and the reference is stable here
     if precision in ("f32", "f16x3"):
@@ -531,7 +531,7 @@ def test_wellconditioned_pass_fraction_over_all_candidates(precision):
              "# id  own_response/tol  gpu_vs_oracle/tol  selected"]
     lines += [f"{int(cand['inst_ids'][i]):3d} {own[i]:8.2f} {used[i]:8.2f}  {'*' if kept[i] else ''}" for i in range(n)]
     os.makedirs("gpurun_out", exist_ok=True)
-    with open(os.path.join("gpurun_out", f"r05_parity_wellconditioned_all_candidates_{precision}.txt"), "w") as f:
+    with open(os.path.join("gpurun_out", f"r06_parity_wellconditioned_all_candidates_{precision}.txt"), "w") as f:
         f.write("\n".join(lines) + "\n")
     print("\n" + "\n".join(lines[:4]))
     assert np.all(ok[kept])
@@ -580,7 +580,7 @@ def test_shape_only_fullsize_state_parity(precision, npts):
     d_r = np.abs(z[:zr.shape[0]] - zr).max(axis=1) / sc[:zr.shape[0]]
     print(f"\nshape-only, {npts} points, {precision}: max |z_gpu - z_oracle| / max|z|: median {np.median(d_o):.2e} max {d_o.max():.2e}; vs the reference: max {d_r.max():.2e}")
     os.makedirs("gpurun_out", exist_ok=True)
-    with open(os.path.join("gpurun_out", f"r05_parity_shape_only_{npts}_{precision}.txt"), "w") as f:
+    with open(os.path.join("gpurun_out", f"r06_parity_shape_only_{npts}_{precision}.txt"), "w") as f:
         f.write(f"# shape_opt_deepsdf, 16 instances x 200 iterations, L = 256, {npts} surface points, GPU {precision}: relative latent deviation per instance\n"
                 "# id  vs_oracle  vs_reference(first 8)\n" +
                 "\n".join(f"{i:2d} {d_o[i]:.2e} {(d_r[i] if i < len(d_r) else float('nan')):.2e}" for i in range(n)) + "\n")

@@ -1,6 +1,6 @@
 """GPU fuzz (round 5): the HIP path against the CPU oracle on the random small cases of
 `scripts/fuzz_oracle_vs_reference.py` -- the generator whose 300-case run pins the ORACLE on the live reference
-(profiles/r05_oracle_fuzz.txt).  Every switch of the loop is drawn at random: L 32 / 64, Sim(3) / SE(3), linear / logistic
+(profiles/r06_oracle_fuzz.txt).  Every switch of the loop is drawn at random: L 32 / 64, Sim(3) / SE(3), linear / logistic
 occupancy (the linear cases run through the round-5 screening pass), occlusion, lm_on / lm_eye / Gauss-Newton, 1-4 frames some
 without foreground or without background rays, 8-120 rays, M = 2 ... 30, background depths 0 / in front / behind, pose known / free,
 start poses off by up to 6 cm (frames turn None), shrunken-fruit decoders (VALID frames that emit zero rays: the exit round 4 had no
